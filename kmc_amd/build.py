@@ -1,0 +1,35 @@
+"""Build kmc_amd/libkmc_hip.so in-tree with hipcc for gfx950 (cross-compiles
+without a GPU).  ``python -m kmc_amd.build``"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, 'csrc', 'kmc_hip.hip')
+OUT = os.path.join(HERE, 'libkmc_hip.so')
+DEPS = [SRC] + [os.path.join(HERE, 'csrc', f) for f in ('kmc_device.h', 'kmc_hop_lds.h')] + \
+       [os.path.join(os.path.dirname(HERE), 'include', 'kmc_hip.h')]
+FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-shared',
+         '-Wno-unused-value']
+
+
+def hipcc():
+    for cand in (shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found')
+
+
+def build(force=False, verbose=False):
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    cmd = [hipcc()] + FLAGS + ['-o', OUT, SRC]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv, verbose=True)

@@ -1,0 +1,862 @@
+// kmc_hip.hip -- C-ABI library of the MI355X (gfx950) hex-lattice KMC engine.
+//
+// Hand-written HIP for CDNA4 only: wave64, DPP scans, LDS-resident replicas.
+// No CPU backend, no MFMA (the path is gather / scan / latency bound).
+// Entry points are declared in include/kmc_hip.h with the reference lines each
+// one replaces.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/kmc_hip.h"
+#include "kmc_device.h"
+#include "kmc_hop_lds.h"
+
+using namespace kmc;
+
+#define KMC_TABLE_ROWS (1u << 18)
+
+// ======================================================================
+// context
+// ======================================================================
+struct kmc_ctx {
+    int device, R, nx, ny, n, window_mode;
+    bool lds_path;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    bool timed;
+    // device state
+    uint8_t* occ;
+    uint32_t* keys;
+    int4* tags;
+    double* table;
+    double* wsum;
+    double* time_total;
+    double* step_time;
+    double* gamma;
+    long long* hist;
+    long long* hops_done;
+    long long* n_exact;
+    int* status;
+    double* barrier;
+    double* scratch_d;     // [R*8] small per-replica scratch
+    // per-call staging
+    double* draws; size_t draws_cap;
+    int32_t* sel; size_t sel_cap;
+    bool have_table, have_keys;
+    int force_exact;
+    double margin_scale;
+    char err[512];
+};
+
+static char g_create_err[512] = "";
+
+static int fail(kmc_ctx* ctx, int code, const char* fmt, ...)
+{
+    char* dst = ctx ? ctx->err : g_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                  \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(ctx, KMC_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+#define CTXCHK(ctx)                                                    \
+    do {                                                               \
+        if (!(ctx)) return fail(nullptr, KMC_EINVAL, "null context"); \
+        HIPCHK(ctx, hipSetDevice((ctx)->device));                      \
+    } while (0)
+
+static void time_begin(kmc_ctx* c) { hipEventRecord(c->ev0, c->stream); }
+static void time_end(kmc_ctx* c) { hipEventRecord(c->ev1, c->stream); c->timed = true; }
+
+// ======================================================================
+// kernels: tables
+// ======================================================================
+// Row T.  One thread per 18-bit key; base table staged in LDS (4 KB).
+// Writes 48 B of rates + 8 B row sum per thread: 14.7 MB, write-bound.
+__global__ __launch_bounds__(256) void fold_table_kernel(const double* __restrict__ base512, double dumbbell,
+                                                          double* __restrict__ table, double* __restrict__ wsum)
+{
+    __shared__ double sb[512];
+    for (int i = threadIdx.x; i < 512; i += 256) sb[i] = base512[i];
+    __syncthreads();
+    const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+    double r[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) r[e] = fold_rate(row, e, sb, dumbbell);
+    double2* out = reinterpret_cast<double2*>(table + (size_t)row * 6);
+    out[0] = make_double2(r[0], r[1]);
+    out[1] = make_double2(r[2], r[3]);
+    out[2] = make_double2(r[4], r[5]);
+    wsum[row] = row_sum6(r);
+}
+
+__global__ __launch_bounds__(256) void wsum_kernel(const double* __restrict__ table, double* __restrict__ wsum)
+{
+    const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+    double r[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) r[e] = table[(size_t)row * 6 + e];
+    wsum[row] = row_sum6(r);
+}
+
+// Row G.  hex_LiCoO2_kmc.py:103-199 + :402-403, one thread per base key.
+// Site q (1..9) of base index t: bit (9 - q) ... the nine free chars MSB first feed
+// key positions 0,1,4,6,8,11,13,14,15 and the cluster sites read positions
+// 0,4,8,1,6,11,13,14,15 (:131) -> free-slot order 0,2,4,1,3,5,6,7,8.
+__device__ __constant__ const int8_t kLceSlot[10] = {-1, 0, 2, 4, 1, 3, 5, 6, 7, 8};
+__device__ __constant__ const int8_t kLceClusters[45][5] = {
+    {1,0,0,0,0},{3,0,0,0,0},{4,0,0,0,0},{7,0,0,0,0},{5,0,0,0,0},{8,0,0,0,0},{6,0,0,0,0},{9,0,0,0,0},{2,0,0,0,0},
+    {6,9,0,0,0},{4,1,0,0,0},{3,7,0,0,0},{4,5,6,0,0},{7,8,9,0,0},{1,2,3,0,0},{5,2,8,0,0},
+    {5,9,0,0,0},{6,8,0,0,0},{5,1,0,0,0},{3,8,0,0,0},{2,4,0,0,0},{2,7,0,0,0},{5,6,0,0,0},{8,9,0,0,0},{5,4,0,0,0},
+    {7,8,0,0,0},{1,2,0,0,0},{2,3,0,0,0},{2,1,4,0,0},{2,3,7,0,0},{5,4,1,0,0},{8,7,3,0,0},
+    {5,6,9,0,0},{8,9,6,0,0},{1,3,0,0,0},{4,6,0,0,0},{7,9,0,0,0},{1,4,5,6,0},{3,7,8,9,0},
+    {5,1,2,3,6},{2,8,0,0,0},{5,8,0,0,0},{5,4,1,2,0},{5,6,9,8,0},{2,3,7,8,0}};
+
+__global__ __launch_bounds__(512) void lce_rates_kernel(const double* __restrict__ eci, double prefactor, double kb_t,
+                                                         double* __restrict__ base512, double* __restrict__ energies)
+{
+    const int t = threadIdx.x;
+    double s[10];
+    s[0] = 0.0;
+#pragma unroll
+    for (int q = 1; q < 10; ++q) s[q] = ((t >> (8 - kLceSlot[q])) & 1) ? -1.0 : 1.0;   // Li -> -1, Vac -> +1 (:130-132)
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 1; q < 10; ++q) tot = tot + s[q];
+    double e = 0.0;
+    e = e + eci[0];
+    e = e + eci[1] * tot;
+    for (int c = 0; c < 45; ++c) {
+        double v = s[kLceClusters[c][0]];
+        for (int q = 1; q < 5 && kLceClusters[c][q]; ++q) v = v * s[kLceClusters[c][q]];
+        e = e + eci[c + 2] * v;
+    }
+    base512[t] = prefactor * exp(-(e) / kb_t);
+    if (energies) energies[t] = e;
+}
+
+// ======================================================================
+// kernels: full rate fill (rows R1, R2) with LDS halo staging
+// ======================================================================
+// One block = a TI x TJ tile of one replica.  The (TI+4) x (TJ+4) occupancy
+// halo (periodic wrap) is staged into LDS with coalesced byte-row reads, then
+// each thread builds the 18-bit keys of its sites from LDS and, if asked,
+// gathers the 48-byte table row into the rate matrix.
+#define RF_TI 16
+#define RF_TJ 64
+__global__ __launch_bounds__(256) void rates_full_kernel(const uint8_t* __restrict__ occ, int nx, int ny, int tiles_i,
+                                                          int tiles_j, const double* __restrict__ table,
+                                                          uint32_t* __restrict__ keys, double* __restrict__ P)
+{
+    __shared__ uint8_t tile[(RF_TI + 4) * (RF_TJ + 4)];
+    const int n = nx * ny;
+    int b = blockIdx.x;
+    const int tj = b % tiles_j; b /= tiles_j;
+    const int ti = b % tiles_i; b /= tiles_i;
+    const int r = b;
+    const uint8_t* o = occ + (size_t)r * n;
+    const int i0 = ti * RF_TI, j0 = tj * RF_TJ;
+    for (int e = threadIdx.x; e < (RF_TI + 4) * (RF_TJ + 4); e += 256) {
+        const int a = e / (RF_TJ + 4), c = e - a * (RF_TJ + 4);
+        int gi = (i0 + a - 2) % nx; if (gi < 0) gi += nx;
+        int gj = (j0 + c - 2) % ny; if (gj < 0) gj += ny;
+        tile[e] = o[gi * ny + gj] & 1u;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < RF_TI * RF_TJ; e += 256) {
+        const int a = e / RF_TJ, c = e - a * RF_TJ;
+        const int gi = i0 + a, gj = j0 + c;
+        if (gi >= nx || gj >= ny) continue;
+        const size_t s = (size_t)r * n + (size_t)gi * ny + gj;
+        uint32_t key = KMC_VACANT;
+        if (tile[(a + 2) * (RF_TJ + 4) + (c + 2)]) {
+            key = 0;
+#pragma unroll
+            for (int p = 0; p < 18; ++p)
+                key = (key << 1) | tile[(a + 2 + kNbI[p]) * (RF_TJ + 4) + (c + 2 + kNbJ[p])];
+        }
+        keys[s] = key;
+        if (P) {
+            double2 v0 = make_double2(0., 0.), v1 = v0, v2 = v0;
+            if (key != KMC_VACANT) {
+                const double2* t = reinterpret_cast<const double2*>(table + (size_t)key * 6);
+                v0 = t[0]; v1 = t[1]; v2 = t[2];
+            }
+            double2* out = reinterpret_cast<double2*>(P + s * 6);
+            out[0] = v0; out[1] = v1; out[2] = v2;
+        }
+    }
+}
+
+// P[s] = T[key[s]] (or zeros): the rate matrix of the stale-key state
+__global__ __launch_bounds__(256) void materialize_rates_kernel(const uint32_t* __restrict__ keys, size_t total,
+                                                                 const double* __restrict__ table, double* __restrict__ P)
+{
+    for (size_t s = (size_t)blockIdx.x * 256 + threadIdx.x; s < total; s += (size_t)gridDim.x * 256) {
+        const uint32_t key = keys[s];
+        double2 v0 = make_double2(0., 0.), v1 = v0, v2 = v0;
+        if (key != KMC_VACANT) {
+            const double2* t = reinterpret_cast<const double2*>(table + (size_t)key * 6);
+            v0 = t[0]; v1 = t[1]; v2 = t[2];
+        }
+        double2* out = reinterpret_cast<double2*>(P + s * 6);
+        out[0] = v0; out[1] = v1; out[2] = v2;
+    }
+}
+
+// Row R3 as a stand-alone call: one window per replica (one wave each).
+__global__ __launch_bounds__(64) void refresh_window_kernel(const uint8_t* __restrict__ occ, int nx, int ny, int mode,
+                                                             const int* __restrict__ se, uint32_t* __restrict__ keys)
+{
+    const int r = blockIdx.x, lane = threadIdx.x, n = nx * ny;
+    const int is = se[r * 4 + 0], js = se[r * 4 + 1], ie = se[r * 4 + 2], je = se[r * 4 + 3];
+    if (is < 0) return;
+    const int imin = is < ie ? is : ie, imax = is < ie ? ie : is;
+    const int jmin = js < je ? js : je, jmax = js < je ? je : js;
+    int i_lo, n_i, j_lo, n_j;
+    if (mode == 0) { i_lo = imin - 2; n_i = imax - imin + 4; j_lo = jmin - 2; n_j = jmax - jmin + 4; }
+    else if (mode == 1) { i_lo = is - 2; n_i = 5; j_lo = js - 2; n_j = 6; }
+    else { i_lo = imin - 2; n_i = imax - imin + 5; j_lo = jmin - 2; n_j = jmax - jmin + 5; }
+    const uint8_t* o = occ + (size_t)r * n;
+    for (int e = lane; e < n_i * n_j; e += 64) {
+        const int a = e / n_j, b = e - a * n_j;
+        int si = (i_lo + a) % nx; if (si < 0) si += nx;
+        int sj = (j_lo + b) % ny; if (sj < 0) sj += ny;
+        keys[(size_t)r * n + si * ny + sj] = o[si * ny + sj] ? key_from_bytes(o, nx, ny, si, sj) : KMC_VACANT;
+    }
+}
+
+__global__ void site_probability_kernel(const uint8_t* __restrict__ occ, int nx, int ny, int i, int j,
+                                        const double* __restrict__ table, uint32_t* key_out, double* rates_out)
+{
+    if (threadIdx.x != 0) return;
+    const uint32_t k = key_from_bytes(occ, nx, ny, i, j);
+    *key_out = k;
+    for (int d = 0; d < 6; ++d) rates_out[d] = table[(size_t)k * 6 + d];
+}
+
+// ======================================================================
+// kernels: lattice fill, tags, observables, exact gamma
+// ======================================================================
+// Exactly n_li sites per replica, uniformly without replacement: every site
+// draws a 64-bit Philox key; the n_li smallest keys (ties by site index) get Li.
+// One wave per replica; the threshold is found by bisection on the key value.
+__global__ __launch_bounds__(64) void fill_random_kernel(uint8_t* __restrict__ occ, int n, const int* __restrict__ n_li,
+                                                          uint32_t seed_lo, uint32_t seed_hi)
+{
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const int want = n_li[r];
+    auto site_key64 = [&](int s) -> unsigned long long {
+        u32x4 c; c.x = (uint32_t)s; c.y = 0; c.z = (uint32_t)r; c.w = KMC_STREAM_FILL;
+        const u32x4 o = philox4x32_10(c, seed_lo, seed_hi);
+        return ((unsigned long long)o.x << 32) | o.y;
+    };
+    // smallest T with count(key <= T) >= want
+    unsigned long long lo = 0, hi = ~0ull;
+    while (lo < hi) {
+        const unsigned long long mid = lo + ((hi - lo) >> 1);
+        long long c = 0;
+        for (int s = lane; s < n; s += 64) c += site_key64(s) <= mid;
+        c = wave_sum_i64(c);
+        if (c >= want) hi = mid; else lo = mid + 1;
+    }
+    const unsigned long long T = lo;
+    long long below = 0;
+    for (int s = lane; s < n; s += 64) below += site_key64(s) < T;
+    below = wave_sum_i64(below);
+    int ties_left = want - (int)below;         // ties at T, lowest site index first
+    for (int s0 = 0; s0 < n; s0 += 64) {
+        const int s = s0 + lane;
+        const unsigned long long k = s < n ? site_key64(s) : ~0ull;
+        const bool tie = s < n && k == T && want > 0;
+        const unsigned long long m = __ballot(tie);
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        const bool li = s < n && want > 0 && (k < T || (tie && rank < ties_left));
+        if (s < n) occ[(size_t)r * n + s] = li ? 1 : 0;
+        ties_left -= __popcll(m);
+        if (ties_left < 0) ties_left = 0;
+    }
+}
+
+// hex_LiCoO2_kmc.py:734-740
+__global__ __launch_bounds__(256) void init_tags_kernel(const uint8_t* __restrict__ occ, int ny, int n, size_t total,
+                                                         int4* __restrict__ tags)
+{
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const int s = (int)(g % n);
+        tags[g] = occ[g] ? make_int4(s / ny, s % ny, 0, 0) : make_int4(-1, 0, 0, 0);
+    }
+}
+
+// Rows D1/D2 on the device: the hex metric r^2 = di^2 + dj^2 + di*dj is an
+// integer, so the per-replica sums are exact and order independent.
+// out[r] = { sum r^2, sum di, sum dj, count }            hex_LiCoO2_kmc.py:567-585
+__global__ __launch_bounds__(256) void msd_kernel(const int4* __restrict__ tags, int nx, int ny, long long* __restrict__ out)
+{
+    const int r = blockIdx.x, n = nx * ny;
+    long long sq = 0, sdi = 0, sdj = 0, cnt = 0;
+    for (int s = threadIdx.x; s < n; s += 256) {
+        const int4 t = tags[(size_t)r * n + s];
+        if (t.x < 0) continue;
+        const int i = s / ny, j = s - i * ny;
+        const long long di = (long long)t.x - ((long long)i + (long long)nx * t.z);
+        const long long dj = (long long)t.y - ((long long)j + (long long)ny * t.w);
+        const long long q = di * di + dj * dj + di * dj;
+        sq += q < 0 ? -q : q; sdi += di; sdj += dj; ++cnt;
+    }
+    __shared__ long long red[4][4];
+    sq = wave_sum_i64(sq); sdi = wave_sum_i64(sdi); sdj = wave_sum_i64(sdj); cnt = wave_sum_i64(cnt);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wv][0] = sq; red[wv][1] = sdi; red[wv][2] = sdj; red[wv][3] = cnt; }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        out[r * 4 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// Row S1 with numpy's association: one lane per replica (every replica walks the
+// same pairwise tree, so the lanes of a wave stay converged).
+__global__ __launch_bounds__(64) void gamma_exact_kernel(const uint32_t* __restrict__ keys, int R, int n,
+                                                          const double* __restrict__ table, double* __restrict__ gamma)
+{
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= R) return;
+    PwFrame st[KMC_PW_DEPTH];
+    const uint32_t* k = keys + (size_t)r * n;
+    auto entry = [&](long e) -> double {
+        const int s = (int)(e / 6);
+        const int d = (int)(e - 6 * (long)s);
+        const uint32_t kk = k[s];
+        return kk == KMC_VACANT ? 0.0 : table[(size_t)kk * 6 + d];
+    };
+    gamma[r] = np_sum_model(6L * n, entry, st);
+}
+
+// ======================================================================
+// host API
+// ======================================================================
+template <class T>
+static int dmalloc(kmc_ctx* c, T** p, size_t count)
+{
+    HIPCHK(c, hipMalloc((void**)p, count * sizeof(T) + 16));
+    return 0;
+}
+
+static size_t host_hop_lds_bytes(int n)
+{
+    return (size_t)8 * n + 512 + (((size_t)4 * n + 15) & ~(size_t)15) + sizeof(PwFrame) * KMC_PW_DEPTH + 64;
+}
+
+extern "C" {
+
+const char* kmc_last_error(kmc_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
+
+int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int window_mode)
+{
+    if (!out) return fail(nullptr, KMC_EINVAL, "kmc_create: out is null");
+    *out = nullptr;
+    if (n_replicas < 1 || nx < 3 || ny < 3 || (long long)nx * ny > (1ll << 24))
+        return fail(nullptr, KMC_EINVAL, "kmc_create: need n_replicas >= 1, nx, ny >= 3, nx*ny <= 2^24 (got %d, %d, %d)",
+                    n_replicas, nx, ny);
+    if (window_mode < 0 || window_mode > 2) return fail(nullptr, KMC_EINVAL, "kmc_create: window_mode must be 0, 1 or 2");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(nullptr, KMC_EHIP, "kmc_create: no HIP device (%s); this engine has no CPU backend",
+                    e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, KMC_EINVAL, "kmc_create: device %d out of range [0, %d)", device, ndev);
+    kmc_ctx* c = (kmc_ctx*)calloc(1, sizeof(kmc_ctx));
+    if (!c) return fail(nullptr, KMC_EINVAL, "kmc_create: out of host memory");
+    c->device = device; c->R = n_replicas; c->nx = nx; c->ny = ny; c->n = nx * ny; c->window_mode = window_mode;
+    c->lds_path = nx >= 5 && ny >= 5 && nx <= 64 && ny <= 64;
+    c->margin_scale = 1.0;
+#define CREATE_CHK(call)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            fail(nullptr, KMC_EHIP, "kmc_create: %s failed: %s", #call, hipGetErrorString(e_)); \
+            kmc_destroy(c);                                                                \
+            return KMC_EHIP;                                                               \
+        }                                                                                  \
+    } while (0)
+    CREATE_CHK(hipSetDevice(device));
+    CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_CHK(hipEventCreate(&c->ev0));
+    CREATE_CHK(hipEventCreate(&c->ev1));
+    const size_t Rn = (size_t)c->R * c->n;
+    CREATE_CHK(hipMalloc((void**)&c->occ, Rn + 16));
+    CREATE_CHK(hipMalloc((void**)&c->keys, Rn * 4 + 16));
+    CREATE_CHK(hipMalloc((void**)&c->tags, Rn * 16 + 16));
+    CREATE_CHK(hipMalloc((void**)&c->table, (size_t)KMC_TABLE_ROWS * 6 * 8));
+    CREATE_CHK(hipMalloc((void**)&c->wsum, (size_t)KMC_TABLE_ROWS * 8));
+    CREATE_CHK(hipMalloc((void**)&c->time_total, c->R * 8));
+    CREATE_CHK(hipMalloc((void**)&c->step_time, c->R * 8));
+    CREATE_CHK(hipMalloc((void**)&c->gamma, c->R * 8));
+    CREATE_CHK(hipMalloc((void**)&c->hist, c->R * 6 * 8));
+    CREATE_CHK(hipMalloc((void**)&c->hops_done, c->R * 8));
+    CREATE_CHK(hipMalloc((void**)&c->n_exact, c->R * 8));
+    CREATE_CHK(hipMalloc((void**)&c->status, c->R * 4));
+    CREATE_CHK(hipMalloc((void**)&c->barrier, c->R * 5 * 8));
+    CREATE_CHK(hipMalloc((void**)&c->scratch_d, c->R * 8 * 8));
+    CREATE_CHK(hipMemsetAsync(c->occ, 0, Rn, c->stream));
+    CREATE_CHK(hipMemsetAsync(c->keys, 0xFF, Rn * 4, c->stream));
+    CREATE_CHK(hipMemsetAsync(c->tags, 0, Rn * 16, c->stream));
+    CREATE_CHK(hipMemsetAsync(c->time_total, 0, c->R * 8, c->stream));
+    CREATE_CHK(hipMemsetAsync(c->step_time, 0, c->R * 8, c->stream));
+    CREATE_CHK(hipMemsetAsync(c->gamma, 0, c->R * 8, c->stream));
+    CREATE_CHK(hipMemsetAsync(c->hist, 0, c->R * 6 * 8, c->stream));
+    CREATE_CHK(hipMemsetAsync(c->hops_done, 0, c->R * 8, c->stream));
+    CREATE_CHK(hipMemsetAsync(c->n_exact, 0, c->R * 8, c->stream));
+    CREATE_CHK(hipMemsetAsync(c->status, 0, c->R * 4, c->stream));
+    if (c->lds_path) {
+        const size_t lds = host_hop_lds_bytes(c->n);
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    CREATE_CHK(hipStreamSynchronize(c->stream));
+#undef CREATE_CHK
+    *out = c;
+    // barrier stats start "empty"
+    kmc_init_displacements(c);
+    return KMC_OK;
+}
+
+int kmc_destroy(kmc_ctx* c)
+{
+    if (!c) return KMC_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    void* bufs[] = {c->occ, c->keys, c->tags, c->table, c->wsum, c->time_total, c->step_time, c->gamma, c->hist,
+                    c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel};
+    for (void* b : bufs) if (b) hipFree(b);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    free(c);
+    return KMC_OK;
+}
+
+int kmc_sync(kmc_ctx* c)
+{
+    CTXCHK(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+}
+
+int kmc_last_kernel_ms(kmc_ctx* c, float* ms)
+{
+    CTXCHK(c);
+    if (!ms) return fail(c, KMC_EINVAL, "kmc_last_kernel_ms: null pointer");
+    if (!c->timed) return fail(c, KMC_ESTATE, "kmc_last_kernel_ms: nothing timed yet");
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return KMC_OK;
+}
+
+int kmc_uses_lds_path(kmc_ctx* c) { return c && c->lds_path ? 1 : 0; }
+int kmc_lds_bytes(kmc_ctx* c) { return c && c->lds_path ? (int)host_hop_lds_bytes(c->n) : 0; }
+
+// ---------------------------------------------------------------- tables
+int kmc_set_base_table(kmc_ctx* c, const double* base512, double dumbbell)
+{
+    CTXCHK(c);
+    if (!base512) return fail(c, KMC_EINVAL, "kmc_set_base_table: null table");
+    double* dbase = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dbase, 512 * 8));
+    HIPCHK(c, hipMemcpyAsync(dbase, base512, 512 * 8, hipMemcpyHostToDevice, c->stream));
+    time_begin(c);
+    fold_table_kernel<<<KMC_TABLE_ROWS / 256, 256, 0, c->stream>>>(dbase, dumbbell, c->table, c->wsum);
+    time_end(c);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(dbase));
+    c->have_table = true;
+    return KMC_OK;
+}
+
+int kmc_set_hex_table(kmc_ctx* c, const double* table)
+{
+    CTXCHK(c);
+    if (!table) return fail(c, KMC_EINVAL, "kmc_set_hex_table: null table");
+    HIPCHK(c, hipMemcpyAsync(c->table, table, (size_t)KMC_TABLE_ROWS * 48, hipMemcpyHostToDevice, c->stream));
+    wsum_kernel<<<KMC_TABLE_ROWS / 256, 256, 0, c->stream>>>(c->table, c->wsum);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_table = true;
+    return KMC_OK;
+}
+
+int kmc_get_hex_table(kmc_ctx* c, double* table)
+{
+    CTXCHK(c);
+    if (!c->have_table) return fail(c, KMC_ESTATE, "kmc_get_hex_table: no table set");
+    HIPCHK(c, hipMemcpyAsync(table, c->table, (size_t)KMC_TABLE_ROWS * 48, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+}
+
+int kmc_generate_base_table(kmc_ctx* c, const double* eci47, double prefactor, double kb_t, double* base512_out,
+                            double* energies_out)
+{
+    CTXCHK(c);
+    if (!eci47 || !base512_out) return fail(c, KMC_EINVAL, "kmc_generate_base_table: null pointer");
+    double* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, (47 + 512 + 512) * 8 + 64));
+    HIPCHK(c, hipMemcpyAsync(d, eci47, 47 * 8, hipMemcpyHostToDevice, c->stream));
+    lce_rates_kernel<<<1, 512, 0, c->stream>>>(d, prefactor, kb_t, d + 48, d + 48 + 512);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(base512_out, d + 48, 512 * 8, hipMemcpyDeviceToHost, c->stream));
+    if (energies_out) HIPCHK(c, hipMemcpyAsync(energies_out, d + 48 + 512, 512 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d));
+    return KMC_OK;
+}
+
+// ---------------------------------------------------------------- lattice
+int kmc_set_lattice(kmc_ctx* c, const int8_t* occ)
+{
+    CTXCHK(c);
+    if (!occ) return fail(c, KMC_EINVAL, "kmc_set_lattice: null pointer");
+    const size_t Rn = (size_t)c->R * c->n;
+    for (size_t s = 0; s < Rn; ++s)
+        if (occ[s] != 0 && occ[s] != 1) return fail(c, KMC_EINVAL, "kmc_set_lattice: occupancy must be 0 or 1 (site %zu holds %d)", s, (int)occ[s]);
+    HIPCHK(c, hipMemcpyAsync(c->occ, occ, Rn, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_keys = false;
+    return KMC_OK;
+}
+
+int kmc_get_lattice(kmc_ctx* c, int8_t* occ)
+{
+    CTXCHK(c);
+    if (!occ) return fail(c, KMC_EINVAL, "kmc_get_lattice: null pointer");
+    HIPCHK(c, hipMemcpyAsync(occ, c->occ, (size_t)c->R * c->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+}
+
+int kmc_fill_random(kmc_ctx* c, const double* conc, uint64_t seed)
+{
+    CTXCHK(c);
+    if (!conc) return fail(c, KMC_EINVAL, "kmc_fill_random: null pointer");
+    int* h = (int*)malloc(sizeof(int) * c->R);
+    for (int r = 0; r < c->R; ++r) {
+        if (!(conc[r] >= 0.0 && conc[r] <= 1.0)) { free(h); return fail(c, KMC_EINVAL, "kmc_fill_random: concentration %g of replica %d not in [0, 1]", conc[r], r); }
+        h[r] = (int)((double)c->nx * c->ny * 1 * conc[r]);          // int(N*N*1*x), hex_LiCoO2_kmc.py:484
+    }
+    int* d = reinterpret_cast<int*>(c->scratch_d);
+    hipError_t e = hipMemcpyAsync(d, h, sizeof(int) * c->R, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    free(h);
+    HIPCHK(c, e);
+    fill_random_kernel<<<c->R, 64, 0, c->stream>>>(c->occ, c->n, d, (uint32_t)seed, (uint32_t)(seed >> 32));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_keys = false;
+    return KMC_OK;
+}
+
+// ---------------------------------------------------------------- rates
+static int launch_rates_full(kmc_ctx* c, double* P)
+{
+    const int ti = (c->nx + RF_TI - 1) / RF_TI, tj = (c->ny + RF_TJ - 1) / RF_TJ;
+    const long long blocks = (long long)c->R * ti * tj;
+    if (blocks > 0x7fffffffLL) return fail(c, KMC_EINVAL, "rates_full: grid too large");
+    rates_full_kernel<<<(unsigned)blocks, 256, 0, c->stream>>>(c->occ, c->nx, c->ny, ti, tj, c->table, c->keys, P);
+    HIPCHK(c, hipGetLastError());
+    return KMC_OK;
+}
+
+int kmc_rates_full(kmc_ctx* c)
+{
+    CTXCHK(c);
+    if (!c->have_table) return fail(c, KMC_ESTATE, "kmc_rates_full: set a rate table first");
+    time_begin(c);
+    int rc = launch_rates_full(c, nullptr);
+    time_end(c);
+    if (rc) return rc;
+    c->have_keys = true;
+    return KMC_OK;
+}
+
+int kmc_get_keys(kmc_ctx* c, uint32_t* keys)
+{
+    CTXCHK(c);
+    if (!keys) return fail(c, KMC_EINVAL, "kmc_get_keys: null pointer");
+    if (!c->have_keys) return fail(c, KMC_ESTATE, "kmc_get_keys: run kmc_rates_full first");
+    HIPCHK(c, hipMemcpyAsync(keys, c->keys, (size_t)c->R * c->n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+}
+
+int kmc_set_keys(kmc_ctx* c, const uint32_t* keys)
+{
+    CTXCHK(c);
+    if (!keys) return fail(c, KMC_EINVAL, "kmc_set_keys: null pointer");
+    const size_t Rn = (size_t)c->R * c->n;
+    for (size_t s = 0; s < Rn; ++s)
+        if (keys[s] != KMC_VACANT_KEY && keys[s] >= KMC_TABLE_ROWS)
+            return fail(c, KMC_EINVAL, "kmc_set_keys: key %u at %zu is not an 18-bit key", keys[s], s);
+    HIPCHK(c, hipMemcpyAsync(c->keys, keys, Rn * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_keys = true;
+    return KMC_OK;
+}
+
+int kmc_get_rates(kmc_ctx* c, double* P)
+{
+    CTXCHK(c);
+    if (!P) return fail(c, KMC_EINVAL, "kmc_get_rates: null pointer");
+    if (!c->have_keys || !c->have_table) return fail(c, KMC_ESTATE, "kmc_get_rates: needs a table and kmc_rates_full");
+    const size_t Rn = (size_t)c->R * c->n;
+    // staged through a bounded device buffer so that 4096 x 64 x 64 (805 MB) needs no 805 MB of HBM
+    const size_t chunk = Rn < ((size_t)1 << 22) ? Rn : ((size_t)1 << 22);
+    double* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, chunk * 48));
+    for (size_t s0 = 0; s0 < Rn; s0 += chunk) {
+        const size_t m = Rn - s0 < chunk ? Rn - s0 : chunk;
+        materialize_rates_kernel<<<2048, 256, 0, c->stream>>>(c->keys + s0, m, c->table, d);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(P + s0 * 6, d, m * 48, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { hipFree(d); HIPCHK(c, e); }
+    }
+    HIPCHK(c, hipFree(d));
+    return KMC_OK;
+}
+
+int kmc_refresh_window(kmc_ctx* c, const int32_t* se)
+{
+    CTXCHK(c);
+    if (!se) return fail(c, KMC_EINVAL, "kmc_refresh_window: null pointer");
+    if (!c->have_keys) return fail(c, KMC_ESTATE, "kmc_refresh_window: run kmc_rates_full (or kmc_set_keys) first");
+    for (int r = 0; r < c->R; ++r) {
+        const int32_t* q = se + 4 * r;
+        if (q[0] < 0) continue;
+        if (q[0] >= c->nx || q[1] < 0 || q[1] >= c->ny || abs(q[2] - q[0]) > 2 || abs(q[3] - q[1]) > 2)
+            return fail(c, KMC_EINVAL, "kmc_refresh_window: replica %d: start (%d,%d) / end (%d,%d) out of range", r, q[0], q[1], q[2], q[3]);
+    }
+    int* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, (size_t)c->R * 16));
+    HIPCHK(c, hipMemcpyAsync(d, se, (size_t)c->R * 16, hipMemcpyHostToDevice, c->stream));
+    refresh_window_kernel<<<c->R, 64, 0, c->stream>>>(c->occ, c->nx, c->ny, c->window_mode, d, c->keys);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d));
+    return KMC_OK;
+}
+
+int kmc_site_probability(kmc_ctx* c, int replica, int i, int j, uint32_t* key, double* rates6)
+{
+    CTXCHK(c);
+    if (!c->have_table) return fail(c, KMC_ESTATE, "kmc_site_probability: set a rate table first");
+    if (replica < 0 || replica >= c->R || i < 0 || i >= c->nx || j < 0 || j >= c->ny)
+        return fail(c, KMC_EINVAL, "kmc_site_probability: replica/site out of range");
+    uint32_t* dk = reinterpret_cast<uint32_t*>(c->scratch_d);
+    double* dr = c->scratch_d + 1;
+    site_probability_kernel<<<1, 64, 0, c->stream>>>(c->occ + (size_t)replica * c->n, c->nx, c->ny, i, j, c->table, dk, dr);
+    HIPCHK(c, hipGetLastError());
+    uint32_t hk; double hr[6];
+    HIPCHK(c, hipMemcpyAsync(&hk, dk, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hr, dr, 48, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (key) *key = hk;
+    if (rates6) memcpy(rates6, hr, 48);
+    return KMC_OK;
+}
+
+// ---------------------------------------------------------------- tags
+int kmc_init_displacements(kmc_ctx* c)
+{
+    CTXCHK(c);
+    const size_t Rn = (size_t)c->R * c->n;
+    init_tags_kernel<<<1024, 256, 0, c->stream>>>(c->occ, c->ny, c->n, Rn, c->tags);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemsetAsync(c->time_total, 0, c->R * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->step_time, 0, c->R * 8, c->stream));
+    double* h = (double*)malloc((size_t)c->R * 5 * 8);
+    for (int r = 0; r < c->R; ++r) { h[r * 5] = NAN; h[r * 5 + 1] = 0; h[r * 5 + 2] = 1e300; h[r * 5 + 3] = -1e300; h[r * 5 + 4] = 0; }
+    hipError_t e = hipMemcpyAsync(c->barrier, h, (size_t)c->R * 5 * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    free(h);
+    HIPCHK(c, e);
+    return KMC_OK;
+}
+
+int kmc_set_displacements(kmc_ctx* c, const int32_t* tags)
+{
+    CTXCHK(c);
+    if (!tags) return fail(c, KMC_EINVAL, "kmc_set_displacements: null pointer");
+    HIPCHK(c, hipMemcpyAsync(c->tags, tags, (size_t)c->R * c->n * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+}
+
+int kmc_get_displacements(kmc_ctx* c, int32_t* tags)
+{
+    CTXCHK(c);
+    if (!tags) return fail(c, KMC_EINVAL, "kmc_get_displacements: null pointer");
+    HIPCHK(c, hipMemcpyAsync(tags, c->tags, (size_t)c->R * c->n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+}
+
+// ---------------------------------------------------------------- hop loop
+int kmc_set_debug(kmc_ctx* c, int force_exact, double margin_scale)
+{
+    CTXCHK(c);
+    if (!(margin_scale >= 1.0)) return fail(c, KMC_EINVAL, "kmc_set_debug: margin_scale must be >= 1");
+    c->force_exact = force_exact != 0;
+    c->margin_scale = margin_scale;
+    return KMC_OK;
+}
+
+int kmc_run(kmc_ctx* c, int64_t n_hops, int presim, const double* draws, uint64_t seed, int32_t* sel_out)
+{
+    CTXCHK(c);
+    if (n_hops < 0) return fail(c, KMC_EINVAL, "kmc_run: n_hops < 0");
+    if (!c->have_table) return fail(c, KMC_ESTATE, "kmc_run: set a rate table first");
+    if (!c->have_keys) return fail(c, KMC_ESTATE, "kmc_run: run kmc_rates_full (or kmc_set_keys) first");
+    if (!c->lds_path) return fail(c, KMC_EINVAL, "kmc_run: lattices beyond 64 x 64 are not served yet (nx=%d, ny=%d)", c->nx, c->ny);
+    if (n_hops == 0) return KMC_OK;
+    const size_t Rh = (size_t)c->R * (size_t)n_hops;
+    if (draws) {
+        if (c->draws_cap < Rh * 2) {
+            if (c->draws) HIPCHK(c, hipFree(c->draws));
+            c->draws = nullptr; c->draws_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->draws, Rh * 16));
+            c->draws_cap = Rh * 2;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->draws, draws, Rh * 16, hipMemcpyHostToDevice, c->stream));
+    }
+    if (sel_out) {
+        if (c->sel_cap < Rh) {
+            if (c->sel) HIPCHK(c, hipFree(c->sel));
+            c->sel = nullptr; c->sel_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->sel, Rh * 4));
+            c->sel_cap = Rh;
+        }
+    }
+    HopParams p;
+    memset(&p, 0, sizeof(p));
+    p.nx = c->nx; p.ny = c->ny; p.n = c->n; p.window_mode = c->window_mode;
+    p.n_hops = n_hops; p.presim = presim != 0; p.force_exact = c->force_exact;
+    // rigorous rounding bound of the certified selection, see kmc_hop_lds.h / DESIGN.md
+    p.mfac = (6.0 * c->n + 256.0) * ldexp(1.0, -53) * 1.001 * c->margin_scale;
+    p.table = c->table; p.wsum = c->wsum; p.occ = c->occ; p.keys = c->keys; p.tags = c->tags;
+    p.draws = draws ? c->draws : nullptr; p.sel = sel_out ? c->sel : nullptr;
+    p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
+    p.time_total = c->time_total; p.step_time = c->step_time; p.gamma = c->gamma; p.hist = c->hist;
+    p.hops_done = c->hops_done; p.n_exact = c->n_exact; p.status = c->status; p.barrier = c->barrier;
+    time_begin(c);
+    hop_lds_kernel<<<c->R, 64, host_hop_lds_bytes(c->n), c->stream>>>(p);
+    time_end(c);
+    HIPCHK(c, hipGetLastError());
+    if (sel_out) {
+        HIPCHK(c, hipMemcpyAsync(sel_out, c->sel, Rh * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (draws) HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller may reuse its buffer
+    return KMC_OK;
+}
+
+int kmc_get_scalars(kmc_ctx* c, double* time, double* step_time, double* gamma, int64_t* hist)
+{
+    CTXCHK(c);
+    if (time) HIPCHK(c, hipMemcpyAsync(time, c->time_total, c->R * 8, hipMemcpyDeviceToHost, c->stream));
+    if (step_time) HIPCHK(c, hipMemcpyAsync(step_time, c->step_time, c->R * 8, hipMemcpyDeviceToHost, c->stream));
+    if (gamma) HIPCHK(c, hipMemcpyAsync(gamma, c->gamma, c->R * 8, hipMemcpyDeviceToHost, c->stream));
+    if (hist) HIPCHK(c, hipMemcpyAsync(hist, c->hist, c->R * 48, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+}
+
+int kmc_set_time(kmc_ctx* c, const double* time)
+{
+    CTXCHK(c);
+    if (!time) return fail(c, KMC_EINVAL, "kmc_set_time: null pointer");
+    HIPCHK(c, hipMemcpyAsync(c->time_total, time, c->R * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+}
+
+int kmc_get_barrier_stats(kmc_ctx* c, double* out)
+{
+    CTXCHK(c);
+    if (!out) return fail(c, KMC_EINVAL, "kmc_get_barrier_stats: null pointer");
+    HIPCHK(c, hipMemcpyAsync(out, c->barrier, (size_t)c->R * 40, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+}
+
+int kmc_get_status(kmc_ctx* c, int32_t* status, int64_t* hops_done, int64_t* n_exact)
+{
+    CTXCHK(c);
+    if (status) HIPCHK(c, hipMemcpyAsync(status, c->status, c->R * 4, hipMemcpyDeviceToHost, c->stream));
+    if (hops_done) HIPCHK(c, hipMemcpyAsync(hops_done, c->hops_done, c->R * 8, hipMemcpyDeviceToHost, c->stream));
+    if (n_exact) HIPCHK(c, hipMemcpyAsync(n_exact, c->n_exact, c->R * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+}
+
+int kmc_gamma_exact(kmc_ctx* c, double* gamma)
+{
+    CTXCHK(c);
+    if (!gamma) return fail(c, KMC_EINVAL, "kmc_gamma_exact: null pointer");
+    if (!c->have_keys || !c->have_table) return fail(c, KMC_ESTATE, "kmc_gamma_exact: needs a table and kmc_rates_full");
+    double* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, (size_t)c->R * 8));
+    gamma_exact_kernel<<<(c->R + 63) / 64, 64, 0, c->stream>>>(c->keys, c->R, c->n, c->table, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(gamma, d, (size_t)c->R * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    HIPCHK(c, e);
+    return KMC_OK;
+}
+
+// ---------------------------------------------------------------- observables
+int kmc_diffusion(kmc_ctx* c, const double* conc, double a, double* dstar, double* dj, double* msd_out)
+{
+    CTXCHK(c);
+    if (!conc || !dstar || !dj) return fail(c, KMC_EINVAL, "kmc_diffusion: null pointer");
+    long long* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, (size_t)c->R * 32));
+    msd_kernel<<<c->R, 256, 0, c->stream>>>(c->tags, c->nx, c->ny, d);
+    long long* h = (long long*)malloc((size_t)c->R * 32);
+    double* t = (double*)malloc((size_t)c->R * 8);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, (size_t)c->R * 32, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t, c->time_total, (size_t)c->R * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    int rc = KMC_OK;
+    if (e != hipSuccess) rc = fail(c, KMC_EHIP, "kmc_diffusion: %s", hipGetErrorString(e));
+    for (int r = 0; rc == KMC_OK && r < c->R; ++r) {
+        // hex_LiCoO2_kmc.py:591-602 (number_of_atoms is a float)
+        const double n_atoms = (double)c->nx * c->ny * 1 * conc[r];
+        if (n_atoms == 0) { rc = fail(c, KMC_EINVAL, "concentration is zero, no atoms to move!"); break; }
+        const double sq = (double)h[r * 4], si = (double)h[r * 4 + 1], sj = (double)h[r * 4 + 2], cnt = (double)h[r * 4 + 3];
+        const double mean_sq = (a * a) * sq / cnt;                         // np.average(np.square(list))
+        const double dj2 = (a * a) * fabs(si * si + sj * sj + si * sj);    // d_j_distance**2
+        const double pref = 1 / (2 * 2 * t[r] / n_atoms);
+        dstar[r] = pref * mean_sq;
+        dj[r] = pref * dj2 / n_atoms;
+        if (msd_out) { msd_out[r * 4] = sq; msd_out[r * 4 + 1] = si; msd_out[r * 4 + 2] = sj; msd_out[r * 4 + 3] = cnt; }
+    }
+    free(h); free(t);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,233 @@
+"""KMCEngine -- numpy-facing wrapper of one C-ABI context (one GPU).
+
+A context holds ``n_replicas`` independent nx x ny lattices (the size x
+concentration x averaging-iteration loops of hex_LiCoO2_kmc.py:679-693) and
+runs the per-hop loop (:484-535) for all of them on the device.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+WINDOW_MODES = {'hex_ref': 0, 'obj_ref': 1, 'full': 2}
+VACANT_KEY = 0xFFFFFFFF
+LATTICE_CONSTANT = 2.8334 * 10 ** (-8)        # hex_LiCoO2_kmc.py:29
+
+
+class KMCError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('kmc error %d: %s' % (code, msg))
+        self.code = code
+
+
+class ReplicaStopped(KMCError):
+    """A replica hit the reference's IndexError / zero-rate condition."""
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+class KMCEngine:
+    def __init__(self, n_replicas, nx, ny=None, window_mode='hex_ref', device=0):
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p()
+        ny = nx if ny is None else ny
+        mode = WINDOW_MODES[window_mode] if isinstance(window_mode, str) else int(window_mode)
+        rc = self._lib.kmc_create(C.byref(self._ctx), int(device), int(n_replicas), int(nx), int(ny), mode)
+        if rc != 0:
+            msg = self._lib.kmc_last_error(None).decode()
+            self._ctx = C.c_void_p()
+            raise KMCError(rc, msg)
+        self.R, self.nx, self.ny, self.device = int(n_replicas), int(nx), int(ny), int(device)
+        self.window_mode = window_mode
+
+    # -- plumbing ----------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self._lib.kmc_last_error(self._ctx).decode()
+            raise (ReplicaStopped if rc == -4 else KMCError)(rc, msg)
+
+    def close(self):
+        if getattr(self, '_ctx', None) is not None and self._ctx.value:
+            self._lib.kmc_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        self._chk(self._lib.kmc_sync(self._ctx))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._chk(self._lib.kmc_last_kernel_ms(self._ctx, C.byref(ms)))
+        return ms.value
+
+    @property
+    def uses_lds_path(self):
+        return bool(self._lib.kmc_uses_lds_path(self._ctx))
+
+    @property
+    def lds_bytes(self):
+        return int(self._lib.kmc_lds_bytes(self._ctx))
+
+    # -- tables --------------------------------------------------------------
+    def set_base_table(self, base512, dumbbell):
+        b = np.ascontiguousarray(base512, dtype=np.float64)
+        if b.shape != (512,):
+            raise ValueError('base table must have 512 entries')
+        self._chk(self._lib.kmc_set_base_table(self._ctx, _ptr(b, C.c_double), float(dumbbell)))
+
+    def set_hex_table(self, table):
+        t = np.ascontiguousarray(table, dtype=np.float64)
+        if t.shape != (1 << 18, 6):
+            raise ValueError('dense table must be (262144, 6)')
+        self._chk(self._lib.kmc_set_hex_table(self._ctx, _ptr(t, C.c_double)))
+
+    def get_hex_table(self):
+        t = np.empty((1 << 18, 6), dtype=np.float64)
+        self._chk(self._lib.kmc_get_hex_table(self._ctx, _ptr(t, C.c_double)))
+        return t
+
+    def generate_base_table(self, eci47, prefactor, kb_t):
+        e = np.ascontiguousarray(eci47, dtype=np.float64)
+        if e.shape != (47,):
+            raise ValueError('need 47 ECIs')
+        base = np.empty(512)
+        en = np.empty(512)
+        self._chk(self._lib.kmc_generate_base_table(self._ctx, _ptr(e, C.c_double), float(prefactor),
+                                                    float(kb_t), _ptr(base, C.c_double), _ptr(en, C.c_double)))
+        return base, en
+
+    # -- lattice -----------------------------------------------------------------
+    def _shape(self, *tail):
+        return (self.R, self.nx, self.ny) + tail
+
+    def set_lattice(self, occ):
+        o = np.ascontiguousarray(occ, dtype=np.int8).reshape(self._shape())
+        self._chk(self._lib.kmc_set_lattice(self._ctx, _ptr(o, C.c_int8)))
+
+    def get_lattice(self):
+        o = np.empty(self._shape(), dtype=np.int8)
+        self._chk(self._lib.kmc_get_lattice(self._ctx, _ptr(o, C.c_int8)))
+        return o
+
+    def fill_random(self, conc, seed):
+        c = np.ascontiguousarray(np.broadcast_to(np.asarray(conc, dtype=np.float64), (self.R,)))
+        self._chk(self._lib.kmc_fill_random(self._ctx, _ptr(c, C.c_double), int(seed)))
+
+    # -- rates -------------------------------------------------------------------
+    def rates_full(self):
+        self._chk(self._lib.kmc_rates_full(self._ctx))
+
+    def get_keys(self):
+        k = np.empty(self._shape(), dtype=np.uint32)
+        self._chk(self._lib.kmc_get_keys(self._ctx, _ptr(k, C.c_uint32)))
+        return k
+
+    def set_keys(self, keys):
+        k = np.ascontiguousarray(keys, dtype=np.uint32).reshape(self._shape())
+        self._chk(self._lib.kmc_set_keys(self._ctx, _ptr(k, C.c_uint32)))
+
+    def get_rates(self):
+        p = np.empty(self._shape(6), dtype=np.float64)
+        self._chk(self._lib.kmc_get_rates(self._ctx, _ptr(p, C.c_double)))
+        return p
+
+    def refresh_window(self, start_end):
+        se = np.ascontiguousarray(start_end, dtype=np.int32).reshape(self.R, 4)
+        self._chk(self._lib.kmc_refresh_window(self._ctx, _ptr(se, C.c_int32)))
+
+    def site_probability(self, replica, i, j):
+        key = C.c_uint32()
+        r = np.empty(6)
+        self._chk(self._lib.kmc_site_probability(self._ctx, int(replica), int(i), int(j),
+                                                 C.byref(key), _ptr(r, C.c_double)))
+        return key.value, r
+
+    # -- tags --------------------------------------------------------------------
+    def init_displacements(self):
+        self._chk(self._lib.kmc_init_displacements(self._ctx))
+
+    def set_displacements(self, tags):
+        t = np.ascontiguousarray(tags, dtype=np.int32).reshape(self._shape(4))
+        self._chk(self._lib.kmc_set_displacements(self._ctx, _ptr(t, C.c_int32)))
+
+    def get_displacements(self):
+        t = np.empty(self._shape(4), dtype=np.int32)
+        self._chk(self._lib.kmc_get_displacements(self._ctx, _ptr(t, C.c_int32)))
+        return t
+
+    def get_reference_tags(self):
+        """Tags in the reference's packing [i0, j0, 100*wi + wj] (:525-526)."""
+        t = self.get_displacements().astype(np.int64)
+        return np.stack([t[..., 0], t[..., 1], 100 * t[..., 2] + t[..., 3]], axis=-1)
+
+    # -- hop loop ----------------------------------------------------------------
+    def run(self, n_hops, presim=False, draws=None, seed=0, want_trace=False):
+        """n_hops hops in every replica.  draws: (R, n_hops, 2) injected uniforms
+        (rho, clock draw) or None for the Philox stream.  Returns the
+        hop_master_index trace (R, n_hops) if want_trace."""
+        d = None
+        if draws is not None:
+            d = np.ascontiguousarray(draws, dtype=np.float64)
+            if d.shape != (self.R, n_hops, 2):
+                raise ValueError('draws must be (R, n_hops, 2), got %r' % (d.shape,))
+        sel = np.empty((self.R, n_hops), dtype=np.int32) if want_trace else None
+        self._chk(self._lib.kmc_run(self._ctx, int(n_hops), int(bool(presim)), _ptr(d, C.c_double),
+                                    int(seed), _ptr(sel, C.c_int32)))
+        return sel
+
+    def scalars(self):
+        t = np.empty(self.R)
+        st = np.empty(self.R)
+        g = np.empty(self.R)
+        h = np.empty((self.R, 6), dtype=np.int64)
+        self._chk(self._lib.kmc_get_scalars(self._ctx, _ptr(t, C.c_double), _ptr(st, C.c_double),
+                                            _ptr(g, C.c_double), _ptr(h, C.c_int64)))
+        return dict(time=t, step_time=st, gamma=g, hist=h)
+
+    def set_time(self, time):
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(time, dtype=np.float64), (self.R,)))
+        self._chk(self._lib.kmc_set_time(self._ctx, _ptr(t, C.c_double)))
+
+    def barrier_stats(self):
+        b = np.empty((self.R, 5))
+        self._chk(self._lib.kmc_get_barrier_stats(self._ctx, _ptr(b, C.c_double)))
+        return dict(last=b[:, 0], sum=b[:, 1], min=b[:, 2], max=b[:, 3], count=b[:, 4])
+
+    def status(self):
+        s = np.empty(self.R, dtype=np.int32)
+        h = np.empty(self.R, dtype=np.int64)
+        e = np.empty(self.R, dtype=np.int64)
+        self._chk(self._lib.kmc_get_status(self._ctx, _ptr(s, C.c_int32), _ptr(h, C.c_int64), _ptr(e, C.c_int64)))
+        return dict(status=s, hops_done=h, n_exact=e)
+
+    def gamma_exact(self):
+        g = np.empty(self.R)
+        self._chk(self._lib.kmc_gamma_exact(self._ctx, _ptr(g, C.c_double)))
+        return g
+
+    def set_debug(self, force_exact=False, margin_scale=1.0):
+        self._chk(self._lib.kmc_set_debug(self._ctx, int(bool(force_exact)), float(margin_scale)))
+
+    # -- observables ---------------------------------------------------------------
+    def diffusion(self, conc, lattice_constant=LATTICE_CONSTANT):
+        c = np.ascontiguousarray(np.broadcast_to(np.asarray(conc, dtype=np.float64), (self.R,)))
+        ds = np.empty(self.R)
+        dj = np.empty(self.R)
+        msd = np.empty((self.R, 4))
+        self._chk(self._lib.kmc_diffusion(self._ctx, _ptr(c, C.c_double), float(lattice_constant),
+                                          _ptr(ds, C.c_double), _ptr(dj, C.c_double), _ptr(msd, C.c_double)))
+        return ds, dj, msd

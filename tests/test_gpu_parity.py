@@ -1,0 +1,340 @@
+"""GPU parity: the HIP engine (through the C ABI) against the oracle.
+
+Bars (north star): lattice state, keys and hop selections bit-exact; rates equal
+to the reference table (<= 1e-12 relative, in practice bit-exact); clocks and
+diffusion coefficients within 1e-12 relative.
+"""
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle as CO          # noqa: E402
+from oracle import kmc_oracle as O         # noqa: E402
+from oracle import philox as PH            # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+TRAJ = sorted(glob.glob(os.path.join(GOLDEN, 'traj_*.npz')))
+RTOL = 1e-12                               # floating-point bar of the north star
+
+
+@pytest.fixture(scope='module')
+def kmc():
+    import kmc_amd
+    return kmc_amd
+
+
+@pytest.fixture(scope='module')
+def tables():
+    t = np.load(os.path.join(GOLDEN, 'tables.npz'))
+    with open(os.path.join(GOLDEN, 'tables.json')) as f:
+        info = json.load(f)
+    return t, info
+
+
+@pytest.fixture(scope='module')
+def dense(tables):
+    return O.build_hex_table(tables[0]['base512_normcons'])
+
+
+def make_engine(kmc, tables, R, nx, ny=None, mode='hex_ref'):
+    eng = kmc.KMCEngine(R, nx, ny, window_mode=mode)
+    eng.set_base_table(tables[0]['base512_normcons'], kmc.tables.dumbbell_rate())
+    return eng
+
+
+# ---------------------------------------------------------------- row T
+def test_table_fold_bit_exact(kmc, tables, dense):
+    t, info = tables
+    with make_engine(kmc, tables, 1, 8) as eng:
+        got = eng.get_hex_table()
+    assert hashlib.sha256(got.astype('<f8').tobytes()).hexdigest() == info['dense_sha256']
+    assert np.array_equal(got[t['sample_rows']], t['sample_rates'])
+    with kmc.KMCEngine(1, 8) as eng:
+        eng.set_base_table(t['base512_master'], kmc.tables.dumbbell_rate())
+        got = eng.get_hex_table()
+        assert np.array_equal(got, O.build_hex_table(t['base512_master']))
+        eng.set_hex_table(dense)
+        assert np.array_equal(eng.get_hex_table(), dense)
+
+
+def test_rate_generation(kmc, tables):
+    """Row G: 512 rates from the cluster expansion, <= 1e-12 of the reference."""
+    t, _ = tables
+    with kmc.KMCEngine(1, 8) as eng:
+        base, en = eng.generate_base_table(kmc.tables.LCE_ECI, 10 ** 13, 0.025)
+    assert np.array_equal(en, t['base512_energies'])
+    np.testing.assert_allclose(base, t['base512_normcons'], rtol=RTOL, atol=0)
+    np.testing.assert_allclose(base, t['base512_regenerated'], rtol=RTOL, atol=0)
+
+
+# ---------------------------------------------------------------- rows R1-R3
+@pytest.mark.parametrize('shape', [(10, 10), (30, 30), (64, 64), (8, 12), (5, 7), (100, 37), (3, 3), (130, 70)])
+def test_rates_full(kmc, tables, dense, shape):
+    nx, ny = shape
+    rs = np.random.RandomState(nx * 1000 + ny)
+    R = 5
+    occ = (rs.rand(R, nx, ny) < rs.rand(R, 1, 1)).astype(np.int8)
+    occ[0] = 0
+    occ[1] = 1
+    with make_engine(kmc, tables, R, nx, ny) as eng:
+        eng.set_lattice(occ)
+        eng.rates_full()
+        keys = eng.get_keys()
+        P = eng.get_rates()
+        assert np.array_equal(eng.get_lattice(), occ)
+        for r in range(R):
+            assert np.array_equal(keys[r], O.all_keys(occ[r]))
+            assert np.array_equal(P[r], O.rates_full(occ[r], dense))
+        # S1: np.sum with numpy's association
+        g = eng.gamma_exact()
+        for r in range(R):
+            assert g[r] == float(np.sum(P[r].reshape(nx, ny, 1, 6)))
+        # R1: single-site query
+        for (i, j) in [(0, 0), (nx - 1, ny - 1), (nx // 2, 1)]:
+            k, rates = eng.site_probability(2, i, j)
+            assert k == O.site_key(occ[2], i, j)
+            assert np.array_equal(rates, dense[k])
+
+
+@pytest.mark.parametrize('mode', ['hex_ref', 'obj_ref', 'full'])
+def test_refresh_window_standalone(kmc, tables, dense, mode):
+    rs = np.random.RandomState(5)
+    nx, ny, R = 12, 9, 6
+    occ = (rs.rand(R, nx, ny) < 0.5).astype(np.int8)
+    with make_engine(kmc, tables, R, nx, ny, mode) as eng:
+        eng.set_lattice(occ)
+        eng.rates_full()
+        occ2 = occ.copy()
+        se = np.zeros((R, 4), dtype=np.int32)
+        P_ref = []
+        for r in range(R):
+            d = r % 6
+            i, j = (0, 0) if r == 0 else (rs.randint(nx), rs.randint(ny))
+            se[r] = (i, j, i + O.HOP_DIRS[d][0], j + O.HOP_DIRS[d][1])
+            occ2[r, i, j] = 0
+            occ2[r, se[r, 2] % nx, se[r, 3] % ny] = 1
+            P = O.rates_full(occ[r], dense)
+            O.rates_window(occ2[r], P, dense, (i, j), (se[r, 2], se[r, 3]), mode)
+            P_ref.append(P)
+        se[5, 0] = -1                     # skipped replica
+        P_ref[5] = O.rates_full(occ[5], dense)
+        eng.set_lattice(occ2)
+        eng.set_keys(np.stack([O.all_keys(o) for o in occ]))
+        eng.refresh_window(se)
+        assert np.array_equal(eng.get_rates(), np.stack(P_ref))
+
+
+# ---------------------------------------------------------------- hop loop vs golden
+def _split_draws(g):
+    nx, ny, conc = int(g['nx']), int(g['ny']), float(g['conc'])
+    n_hops = int(nx * ny * conc)
+    npre, nsim = int(g['n_presim']) * n_hops, int(g['n_sim']) * n_hops
+    d = g['draws']
+    d_pre = np.stack([d[:npre], np.ones(npre)], axis=1)
+    d_sim = d[npre:].reshape(nsim, 2)
+    return n_hops, d_pre, d_sim
+
+
+@pytest.mark.parametrize('force_exact', [False, True], ids=['certified', 'exact'])
+@pytest.mark.parametrize('path', TRAJ, ids=[os.path.basename(p)[5:-4] for p in TRAJ])
+def test_golden_trajectory(kmc, tables, dense, path, force_exact):
+    g = np.load(path)
+    nx, ny, conc = int(g['nx']), int(g['ny']), float(g['conc'])
+    mode = 'obj_ref' if int(g['oo_window']) else 'hex_ref'
+    n_hops, d_pre, d_sim = _split_draws(g)
+    with make_engine(kmc, tables, 1, nx, ny, mode) as eng:
+        eng.set_debug(force_exact=force_exact)
+        eng.set_lattice(g['occ0'][None])
+        eng.rates_full()
+        assert np.array_equal(eng.get_rates()[0], g['P0'])
+        idx1 = eng.run(len(d_pre), presim=True, draws=d_pre[None], want_trace=True)
+        eng.init_displacements()
+        # one kmc_step per call, like the reference's loop (:745-758)
+        idx2, step_times = [], []
+        for s in range(int(g['n_sim'])):
+            idx2.append(eng.run(n_hops, presim=False, draws=d_sim[None, s * n_hops:(s + 1) * n_hops], want_trace=True))
+            step_times.append(eng.scalars()['step_time'][0])
+        idx = np.concatenate([idx1[0]] + [i[0] for i in idx2])
+        assert np.array_equal(idx, g['idx'])
+        assert np.array_equal(eng.get_lattice()[0], g['occ_final'])
+        assert np.array_equal(eng.get_reference_tags()[0], g['tags_final'])
+        assert np.array_equal(eng.get_rates()[0], g['P_final'])
+        sc = eng.scalars()
+        assert np.array_equal(sc['hist'][0], g['hist'].astype(np.int64))
+        np.testing.assert_allclose(step_times, g['step_times'], rtol=RTOL)
+        np.testing.assert_allclose(sc['time'][0], float(g['total_time']), rtol=RTOL)
+        ds, dj, msd = eng.diffusion(conc)
+        np.testing.assert_allclose(ds[0], float(g['d_star']), rtol=RTOL)
+        np.testing.assert_allclose(dj[0], float(g['d_j']), rtol=RTOL)
+        st = eng.status()
+        assert st['status'][0] == 0 and st['hops_done'][0] == idx.size
+        assert st['n_exact'][0] == (idx.size if force_exact else 0)
+        bar = eng.barrier_stats()
+        if not g['barriers'].size:
+            pass
+        elif force_exact:
+            # exact path evaluates the reference's own (cancelling) expression
+            np.testing.assert_allclose(bar['last'][0], g['barriers'][-1], rtol=RTOL)
+        else:
+            np.testing.assert_allclose(bar['last'][0], g['barriers'][-1], rtol=1e-6)
+        stale = np.any(eng.get_rates()[0] != O.rates_full(g['occ_final'], dense), axis=-1)
+        assert np.array_equal(stale, g['stale_mask'])
+        np.testing.assert_allclose(sc['gamma'][0], np.sum(g['P_final']), rtol=RTOL)
+
+
+# ---------------------------------------------------------------- hop loop vs C oracle
+def _oracle_run(occ, dense, mode, draws_pre, draws_sim, conc):
+    rep = CO.Replica(occ, dense, mode)
+    _, i1, _ = rep.run(draws_pre, True)
+    rep.init_tags()
+    _, i2, _ = rep.run(draws_sim, False)
+    return rep, np.concatenate([i1, i2])
+
+
+@pytest.mark.parametrize('cfg', [
+    # nx, ny, R, hops_pre, hops_sim, mode, margin_scale
+    (64, 64, 6, 1500, 3000, 'hex_ref', 1.0),
+    (64, 64, 3, 500, 1500, 'full', 1.0),
+    (64, 64, 3, 500, 1500, 'obj_ref', 1.0),
+    (30, 30, 8, 900, 2000, 'hex_ref', 1.0),
+    (64, 33, 4, 400, 1200, 'hex_ref', 1.0),
+    (5, 5, 4, 100, 400, 'hex_ref', 1.0),
+    (6, 64, 4, 100, 600, 'full', 1.0),
+    # inflated margin: a few percent of the hops take the exact path, mixed in
+    (30, 30, 4, 600, 1500, 'hex_ref', 3e7),
+    (64, 64, 2, 100, 300, 'hex_ref', 1.5e6),
+], ids=lambda c: '%dx%d-%s-m%g' % (c[0], c[1], c[5], c[6]))
+def test_random_ensemble_vs_oracle(kmc, tables, dense, cfg):
+    nx, ny, R, hp, hs, mode, mscale = cfg
+    rs = np.random.RandomState(nx * 7 + ny + R)
+    conc = np.linspace(0.15, 0.85, R)
+    occ = np.stack([(rs.rand(nx, ny) < c).astype(np.int8) for c in conc])
+    d_pre = np.stack([rs.rand(R, hp), np.ones((R, hp))], axis=-1)
+    d_sim = rs.rand(R, hs, 2)
+    with make_engine(kmc, tables, R, nx, ny, mode) as eng:
+        eng.set_debug(force_exact=False, margin_scale=mscale)
+        eng.set_lattice(occ)
+        eng.rates_full()
+        i1 = eng.run(hp, presim=True, draws=d_pre, want_trace=True)
+        eng.init_displacements()
+        i2 = eng.run(hs, presim=False, draws=d_sim, want_trace=True)
+        got_idx = np.concatenate([i1, i2], axis=1)
+        lat, tags, P, sc, st = eng.get_lattice(), eng.get_reference_tags(), eng.get_rates(), eng.scalars(), eng.status()
+        ds, dj, _ = eng.diffusion(occ.reshape(R, -1).mean(axis=1))
+        gex = eng.gamma_exact()
+    for r in range(R):
+        rep, idx = _oracle_run(occ[r], dense, mode, d_pre[r], d_sim[r], conc[r])
+        assert np.array_equal(got_idx[r], idx), 'replica %d' % r
+        assert np.array_equal(lat[r], rep.occ)
+        assert np.array_equal(tags[r], rep.tags)
+        assert np.array_equal(P[r], rep.P)
+        assert np.array_equal(sc['hist'][r], rep.hist.astype(np.int64))
+        np.testing.assert_allclose(sc['time'][r], rep.time.value, rtol=RTOL)
+        assert gex[r] == float(np.sum(rep.P.reshape(nx, ny, 1, 6)))
+        np.testing.assert_allclose(sc['gamma'][r], gex[r], rtol=RTOL)
+        out = rep.diffusion(float(occ[r].mean()))
+        np.testing.assert_allclose(ds[r], out[0], rtol=RTOL)
+        np.testing.assert_allclose(dj[r], out[1], rtol=RTOL)
+    assert not st['status'].any()
+    if mscale > 1:
+        assert st['n_exact'].sum() > 0, 'inflated margin should exercise the exact path'
+        assert st['n_exact'].sum() < 0.5 * R * (hp + hs)
+    else:
+        assert st['n_exact'].sum() <= 1
+
+
+# ---------------------------------------------------------------- RNG streams / fill
+def test_fill_random_matches_philox(kmc, tables):
+    R, nx, ny = 7, 30, 17
+    conc = np.array([0.0, 0.1, 0.33, 0.5, 0.77, 0.999, 1.0])
+    with make_engine(kmc, tables, R, nx, ny) as eng:
+        eng.fill_random(conc, 0xDEADBEEF12345)
+        occ = eng.get_lattice()
+    for r in range(R):
+        assert occ[r].sum() == int(nx * ny * 1 * conc[r])
+        assert np.array_equal(occ[r], PH.fill_lattice(0xDEADBEEF12345, r, nx, ny, conc[r]))
+
+
+def test_philox_stream_run_matches_injected(kmc, tables, dense):
+    """Production mode (draws = NULL) must consume exactly the documented Philox
+    stream, continuing across kmc_run calls."""
+    R, nx, seed = 5, 20, 0x1234567890ABCDEF
+    with make_engine(kmc, tables, R, nx) as eng:
+        eng.fill_random(0.4, 42)
+        occ = eng.get_lattice()
+        eng.rates_full()
+        i1 = eng.run(300, presim=True, seed=seed, want_trace=True)
+        eng.init_displacements()
+        i2 = eng.run(500, presim=False, seed=seed, want_trace=True)
+        i3 = eng.run(77, presim=False, seed=seed, want_trace=True)
+        lat, tags, sc = eng.get_lattice(), eng.get_reference_tags(), eng.scalars()
+    for r in range(R):
+        d = PH.hop_draws(seed, r, 0, 877)
+        rep = CO.Replica(occ[r], dense, 'hex_ref')
+        _, j1, _ = rep.run(d[:300], True)
+        rep.init_tags()
+        _, j2, _ = rep.run(d[300:], False)
+        assert np.array_equal(np.concatenate([i1[r], i2[r], i3[r]]), np.concatenate([j1, j2]))
+        assert np.array_equal(lat[r], rep.occ) and np.array_equal(tags[r], rep.tags)
+        np.testing.assert_allclose(sc['time'][r], rep.time.value, rtol=RTOL)
+
+
+# ---------------------------------------------------------------- edges
+def test_selection_edges(kmc, tables, dense):
+    """rho == 0 picks index 0 (searchsorted left); rho above cumsum[-1]/gamma is the
+    reference's IndexError -> the replica stops with KMC_ST_OVERFLOW; a lattice
+    with no possible hop stops with KMC_ST_ZERO_GAMMA.  """
+    nx = 10
+    rs = np.random.RandomState(0)
+    occ = (rs.rand(3, nx, nx) < 0.5).astype(np.int8)
+    occ[2] = 1                                           # full lattice: gamma == 0
+    draws = rs.rand(3, 40, 2)
+    draws[0, 10, 0] = 0.0
+    draws[1, 25, 0] = 1.0
+    with make_engine(kmc, tables, 3, nx) as eng:
+        eng.set_lattice(occ)
+        eng.rates_full()
+        eng.init_displacements()
+        idx = eng.run(40, presim=False, draws=draws, want_trace=True)
+        st = eng.status()
+        lat, tags, P = eng.get_lattice(), eng.get_reference_tags(), eng.get_rates()
+    rep = CO.Replica(occ[0], dense)
+    rep.init_tags()
+    done, ref_idx, _ = rep.run(draws[0], False)
+    assert done == 40 and ref_idx[10] == 0
+    assert np.array_equal(idx[0], ref_idx) and np.array_equal(lat[0], rep.occ)
+    assert np.array_equal(tags[0], rep.tags) and np.array_equal(P[0], rep.P)
+    rep1 = CO.Replica(occ[1], dense)
+    rep1.init_tags()
+    done1, ref1, _ = rep1.run(draws[1], False)
+    if done1 < 40:                                       # cumsum[-1]/gamma < 1.0 for this state
+        assert st['status'][1] == 1 and st['hops_done'][1] == done1
+        assert np.array_equal(idx[1, :done1], ref1[:done1]) and (idx[1, done1:] == -1).all()
+        assert np.array_equal(lat[1], rep1.occ) and np.array_equal(P[1], rep1.P)
+    else:
+        assert st['status'][1] == 0 and np.array_equal(idx[1], ref1)
+    assert st['status'][2] == 2 and st['hops_done'][2] == 0 and (idx[2] == -1).all()
+    assert st['status'][0] == 0
+
+
+def test_errors_are_loud(kmc, tables):
+    with kmc.KMCEngine(1, 10) as eng:
+        with pytest.raises(kmc.KMCError, match='table'):
+            eng.rates_full()
+        eng.set_base_table(tables[0]['base512_normcons'], kmc.tables.dumbbell_rate())
+        with pytest.raises(kmc.KMCError, match='rates_full'):
+            eng.run(10)
+        with pytest.raises(kmc.KMCError, match='0 or 1'):
+            eng.set_lattice(np.full((1, 10, 10), -1, dtype=np.int8))
+        with pytest.raises(kmc.KMCError, match='concentration is zero'):
+            eng.diffusion(0.0)
+    with pytest.raises(kmc.KMCError):
+        kmc.KMCEngine(1, 2)
+    with pytest.raises(kmc.KMCError, match='device'):
+        kmc.KMCEngine(1, 10, device=99)
