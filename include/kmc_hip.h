@@ -52,6 +52,10 @@ int kmc_sync(kmc_ctx* ctx);
 /* device time (ms, HIP events on the context's stream) of the last kmc_run /
  * kmc_rates_full / kmc_set_base_table launch */
 int kmc_last_kernel_ms(kmc_ctx* ctx, float* ms);
+/* device time (ms) of each of the last (up to 64) hop-kernel launches of kmc_run /
+ * kmc_run_counts, oldest first: HIP events recorded on the context's stream
+ * around every launch.  Synchronises the stream. */
+int kmc_run_kernel_times(kmc_ctx* ctx, float* ms, int max_n, int* n_out);
 
 /* ---- rate tables (row T) --------------------------------------------- */
 /* Folds a 512-entry base table into the 2^18 x 6 device table on the GPU:
@@ -110,6 +114,10 @@ int kmc_get_displacements(kmc_ctx* ctx, int32_t* tags);
  * hop stops there with its state consistent; see kmc_get_status. */
 int kmc_run(kmc_ctx* ctx, int64_t n_hops, int presim, const double* draws, uint64_t seed,
             int32_t* sel_out);
+/* Same loop with a hop count per replica (Philox stream only): one reference
+ * "KMC step" is int(nx*ny*x) hops (:484), which differs between the
+ * concentrations of a sweep (hex_LiCoO2_kmc.py:686). */
+int kmc_run_counts(kmc_ctx* ctx, const int64_t* n_hops /* [R] */, int presim, uint64_t seed);
 /* time [R]: total_time (:754); step_time [R]: clock advance of the last kmc_run
  * (time_step_per_kmcstep :531); gamma [R]: rate sum after the last hop;
  * hist [R][6]: hop_histogram (:535).  Any pointer may be NULL. */

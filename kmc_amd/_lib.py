@@ -25,6 +25,7 @@ SIGNATURES = {
     'kmc_last_error': (C.c_char_p, [_ctx]),
     'kmc_sync': (C.c_int, [_ctx]),
     'kmc_last_kernel_ms': (C.c_int, [_ctx, _fp]),
+    'kmc_run_kernel_times': (C.c_int, [_ctx, _fp, C.c_int, C.POINTER(C.c_int)]),
     'kmc_set_base_table': (C.c_int, [_ctx, _dp, C.c_double]),
     'kmc_set_hex_table': (C.c_int, [_ctx, _dp]),
     'kmc_get_hex_table': (C.c_int, [_ctx, _dp]),
@@ -42,6 +43,7 @@ SIGNATURES = {
     'kmc_set_displacements': (C.c_int, [_ctx, _i32p]),
     'kmc_get_displacements': (C.c_int, [_ctx, _i32p]),
     'kmc_run': (C.c_int, [_ctx, C.c_int64, C.c_int, _dp, C.c_uint64, _i32p]),
+    'kmc_run_counts': (C.c_int, [_ctx, _i64p, C.c_int, C.c_uint64]),
     'kmc_get_scalars': (C.c_int, [_ctx, _dp, _dp, _dp, _i64p]),
     'kmc_set_time': (C.c_int, [_ctx, _dp]),
     'kmc_get_barrier_stats': (C.c_int, [_ctx, _dp]),

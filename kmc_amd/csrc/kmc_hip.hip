@@ -18,6 +18,7 @@
 using namespace kmc;
 
 #define KMC_TABLE_ROWS (1u << 18)
+#define KMC_EV_RING 64
 
 // ======================================================================
 // context
@@ -28,6 +29,8 @@ struct kmc_ctx {
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     bool timed;
+    hipEvent_t run_ev[KMC_EV_RING][2];   // HIP events around the last hop-kernel launches
+    long long run_launches;
     // device state
     uint8_t* occ;
     uint32_t* keys;
@@ -395,6 +398,7 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_CHK(hipEventCreate(&c->ev0));
     CREATE_CHK(hipEventCreate(&c->ev1));
+    for (int k = 0; k < KMC_EV_RING; ++k) { CREATE_CHK(hipEventCreate(&c->run_ev[k][0])); CREATE_CHK(hipEventCreate(&c->run_ev[k][1])); }
     const size_t Rn = (size_t)c->R * c->n;
     CREATE_CHK(hipMalloc((void**)&c->occ, Rn + 16));
     CREATE_CHK(hipMalloc((void**)&c->keys, Rn * 4 + 16));
@@ -442,6 +446,7 @@ int kmc_destroy(kmc_ctx* c)
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    for (int k = 0; k < KMC_EV_RING; ++k) for (int q = 0; q < 2; ++q) if (c->run_ev[k][q]) hipEventDestroy(c->run_ev[k][q]);
     if (c->stream) hipStreamDestroy(c->stream);
     free(c);
     return KMC_OK;
@@ -461,6 +466,21 @@ int kmc_last_kernel_ms(kmc_ctx* c, float* ms)
     if (!c->timed) return fail(c, KMC_ESTATE, "kmc_last_kernel_ms: nothing timed yet");
     HIPCHK(c, hipEventSynchronize(c->ev1));
     HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return KMC_OK;
+}
+
+int kmc_run_kernel_times(kmc_ctx* c, float* ms, int max_n, int* n_out)
+{
+    CTXCHK(c);
+    if (!ms || !n_out || max_n < 0) return fail(c, KMC_EINVAL, "kmc_run_kernel_times: bad arguments");
+    long long n = c->run_launches < KMC_EV_RING ? c->run_launches : KMC_EV_RING;
+    if (n > max_n) n = max_n;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (long long k = 0; k < n; ++k) {          // oldest first
+        const int slot = (int)((c->run_launches - n + k) % KMC_EV_RING);
+        HIPCHK(c, hipEventElapsedTime(&ms[k], c->run_ev[slot][0], c->run_ev[slot][1]));
+    }
+    *n_out = (int)n;
     return KMC_OK;
 }
 
@@ -722,9 +742,9 @@ int kmc_set_debug(kmc_ctx* c, int force_exact, double margin_scale)
     return KMC_OK;
 }
 
-int kmc_run(kmc_ctx* c, int64_t n_hops, int presim, const double* draws, uint64_t seed, int32_t* sel_out)
+static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presim, const double* draws, uint64_t seed,
+                    int32_t* sel_out)
 {
-    CTXCHK(c);
     if (n_hops < 0) return fail(c, KMC_EINVAL, "kmc_run: n_hops < 0");
     if (!c->have_table) return fail(c, KMC_ESTATE, "kmc_run: set a rate table first");
     if (!c->have_keys) return fail(c, KMC_ESTATE, "kmc_run: run kmc_rates_full (or kmc_set_keys) first");
@@ -748,10 +768,16 @@ int kmc_run(kmc_ctx* c, int64_t n_hops, int presim, const double* draws, uint64_
             c->sel_cap = Rh;
         }
     }
+    long long* dcounts = nullptr;
+    if (counts) {
+        dcounts = reinterpret_cast<long long*>(c->scratch_d);
+        HIPCHK(c, hipMemcpyAsync(dcounts, counts, (size_t)c->R * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     HopParams p;
     memset(&p, 0, sizeof(p));
     p.nx = c->nx; p.ny = c->ny; p.n = c->n; p.window_mode = c->window_mode;
-    p.n_hops = n_hops; p.presim = presim != 0; p.force_exact = c->force_exact;
+    p.n_hops = n_hops; p.n_hops_r = dcounts; p.presim = presim != 0; p.force_exact = c->force_exact;
     // rigorous rounding bound of the certified selection, see kmc_hop_lds.h / DESIGN.md
     p.mfac = (6.0 * c->n + 256.0) * ldexp(1.0, -53) * 1.001 * c->margin_scale;
     p.table = c->table; p.wsum = c->wsum; p.occ = c->occ; p.keys = c->keys; p.tags = c->tags;
@@ -759,9 +785,13 @@ int kmc_run(kmc_ctx* c, int64_t n_hops, int presim, const double* draws, uint64_
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
     p.time_total = c->time_total; p.step_time = c->step_time; p.gamma = c->gamma; p.hist = c->hist;
     p.hops_done = c->hops_done; p.n_exact = c->n_exact; p.status = c->status; p.barrier = c->barrier;
+    const int slot = (int)(c->run_launches % KMC_EV_RING);
     time_begin(c);
+    HIPCHK(c, hipEventRecord(c->run_ev[slot][0], c->stream));
     hop_lds_kernel<<<c->R, 64, host_hop_lds_bytes(c->n), c->stream>>>(p);
+    HIPCHK(c, hipEventRecord(c->run_ev[slot][1], c->stream));
     time_end(c);
+    ++c->run_launches;
     HIPCHK(c, hipGetLastError());
     if (sel_out) {
         HIPCHK(c, hipMemcpyAsync(sel_out, c->sel, Rh * 4, hipMemcpyDeviceToHost, c->stream));
@@ -769,6 +799,24 @@ int kmc_run(kmc_ctx* c, int64_t n_hops, int presim, const double* draws, uint64_
     }
     if (draws) HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller may reuse its buffer
     return KMC_OK;
+}
+
+int kmc_run(kmc_ctx* c, int64_t n_hops, int presim, const double* draws, uint64_t seed, int32_t* sel_out)
+{
+    CTXCHK(c);
+    return run_impl(c, n_hops, nullptr, presim, draws, seed, sel_out);
+}
+
+int kmc_run_counts(kmc_ctx* c, const int64_t* n_hops, int presim, uint64_t seed)
+{
+    CTXCHK(c);
+    if (!n_hops) return fail(c, KMC_EINVAL, "kmc_run_counts: null pointer");
+    int64_t mx = 0;
+    for (int r = 0; r < c->R; ++r) {
+        if (n_hops[r] < 0) return fail(c, KMC_EINVAL, "kmc_run_counts: negative hop count for replica %d", r);
+        if (n_hops[r] > mx) mx = n_hops[r];
+    }
+    return run_impl(c, mx, n_hops, presim, nullptr, seed, nullptr);
 }
 
 int kmc_get_scalars(kmc_ctx* c, double* time, double* step_time, double* gamma, int64_t* hist)

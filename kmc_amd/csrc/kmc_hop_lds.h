@@ -28,7 +28,8 @@ namespace kmc {
 
 struct HopParams {
     int nx, ny, n, window_mode;
-    long long n_hops;
+    long long n_hops;            // hops per replica (stride of draws / sel)
+    const long long* n_hops_r;   // [R] per-replica hop counts (<= n_hops) or null
     int presim, force_exact;
     double mfac;                 // certification margin = gamma * mfac
     const double* table;         // [2^18][6]
@@ -141,8 +142,9 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
     int pend_src = 0, pend_dst = 0, pend_dwi = 0, pend_dwj = 0;
     int4 pend_tag = make_int4(0, 0, 0, 0);
 
-    for (long long h0 = 0; h0 < p.n_hops && status == 0; h0 += KMC_WAVE) {
-        const int cnt = (int)((p.n_hops - h0) < KMC_WAVE ? (p.n_hops - h0) : KMC_WAVE);
+    const long long my_hops = p.n_hops_r ? p.n_hops_r[r] : p.n_hops;
+    for (long long h0 = 0; h0 < my_hops && status == 0; h0 += KMC_WAVE) {
+        const int cnt = (int)((my_hops - h0) < KMC_WAVE ? (my_hops - h0) : KMC_WAVE);
         // ---- uniforms for the next 64 hops, one hop per lane --------------
         double rho_v = 0.5, u_v = 1.0;
         if (lane < cnt) {

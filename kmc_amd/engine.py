@@ -74,6 +74,13 @@ class KMCEngine:
         self._chk(self._lib.kmc_last_kernel_ms(self._ctx, C.byref(ms)))
         return ms.value
 
+    def run_kernel_times(self, max_n=64):
+        """ms of the last hop-kernel launches (HIP events on the engine's stream)."""
+        buf = (C.c_float * max_n)()
+        n = C.c_int()
+        self._chk(self._lib.kmc_run_kernel_times(self._ctx, buf, max_n, C.byref(n)))
+        return [buf[k] for k in range(n.value)]
+
     @property
     def uses_lds_path(self):
         return bool(self._lib.kmc_uses_lds_path(self._ctx))
@@ -188,6 +195,11 @@ class KMCEngine:
         self._chk(self._lib.kmc_run(self._ctx, int(n_hops), int(bool(presim)), _ptr(d, C.c_double),
                                     int(seed), _ptr(sel, C.c_int32)))
         return sel
+
+    def run_counts(self, n_hops, presim=False, seed=0):
+        """Per-replica hop counts (Philox stream): concentration sweeps."""
+        n = np.ascontiguousarray(np.broadcast_to(np.asarray(n_hops, dtype=np.int64), (self.R,)))
+        self._chk(self._lib.kmc_run_counts(self._ctx, _ptr(n, C.c_int64), int(bool(presim)), int(seed)))
 
     def scalars(self):
         t = np.empty(self.R)
