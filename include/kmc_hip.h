@@ -142,6 +142,10 @@ int kmc_set_debug(kmc_ctx* ctx, int force_exact, double margin_scale);
 int kmc_diffusion(kmc_ctx* ctx, const double* conc /* [R] */, double lattice_constant,
                   double* dstar /* [R] */, double* dj /* [R] */, double* msd_out);
 
+/* get_distance, hex_LiCoO2_kmc.py:558-586: distances_travelled_matrix * a per site
+ * (0 where vacant); the list and the vector sum follow from it and msd_out. */
+int kmc_get_distances(kmc_ctx* ctx, double lattice_constant, double* matrix /* [R][nx][ny] */);
+
 /* ---- introspection ------------------------------------------------------ */
 /* 1 if the LDS-resident one-wave-per-replica hop kernel serves this context,
  * 0 if the global-memory workgroup kernel does (nx or ny > 64) */

@@ -329,6 +329,26 @@ __global__ __launch_bounds__(256) void msd_kernel(const int4* __restrict__ tags,
         out[r * 4 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
+// Row D1, per site: sqrt(|di^2 + dj^2 + di*dj|) * a (0 where vacant)   hex_LiCoO2_kmc.py:570-578
+__global__ __launch_bounds__(256) void distance_kernel(const int4* __restrict__ tags, int nx, int ny, size_t total, double a,
+                                                        double* __restrict__ out)
+{
+    const int n = nx * ny;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const int4 t = tags[g];
+        double v = 0.0;
+        if (t.x >= 0) {
+            const int s = (int)(g % n);
+            const int i = s / ny, j = s - i * ny;
+            const long long di = (long long)t.x - ((long long)i + (long long)nx * t.z);
+            const long long dj = (long long)t.y - ((long long)j + (long long)ny * t.w);
+            const long long q = di * di + dj * dj + di * dj;
+            v = sqrt(fabs((double)q)) * a;
+        }
+        out[g] = v;
+    }
+}
+
 // Row S1 with numpy's association: one lane per replica (every replica walks the
 // same pairwise tree, so the lanes of a wave stay converged).
 __global__ __launch_bounds__(64) void gamma_exact_kernel(const uint32_t* __restrict__ keys, int R, int n,
@@ -905,6 +925,22 @@ int kmc_diffusion(kmc_ctx* c, const double* conc, double a, double* dstar, doubl
     }
     free(h); free(t);
     return rc;
+}
+
+int kmc_get_distances(kmc_ctx* c, double a, double* matrix)
+{
+    CTXCHK(c);
+    if (!matrix) return fail(c, KMC_EINVAL, "kmc_get_distances: null pointer");
+    const size_t Rn = (size_t)c->R * c->n;
+    double* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, Rn * 8));
+    distance_kernel<<<1024, 256, 0, c->stream>>>(c->tags, c->nx, c->ny, Rn, a, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(matrix, d, Rn * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    HIPCHK(c, e);
+    return KMC_OK;
 }
 
 }  // extern "C"

@@ -243,3 +243,9 @@ class KMCEngine:
         self._chk(self._lib.kmc_diffusion(self._ctx, _ptr(c, C.c_double), float(lattice_constant),
                                           _ptr(ds, C.c_double), _ptr(dj, C.c_double), _ptr(msd, C.c_double)))
         return ds, dj, msd
+
+    def distances(self, lattice_constant=LATTICE_CONSTANT):
+        """distances_travelled_matrix * a (hex_LiCoO2_kmc.py:577-578), (R, nx, ny)."""
+        m = np.empty(self._shape(), dtype=np.float64)
+        self._chk(self._lib.kmc_get_distances(self._ctx, float(lattice_constant), _ptr(m, C.c_double)))
+        return m

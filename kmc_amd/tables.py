@@ -49,6 +49,7 @@ class _Restricted(pickle.Unpickler):
     _ALLOWED = {
         ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
         ('numpy', 'ndarray'), ('numpy', 'dtype'),
+        ('_codecs', 'encode'),          # py3-written protocol-2 arrays: str -> bytes, no side effects
     }
 
     def find_class(self, module, name):

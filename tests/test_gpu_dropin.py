@@ -1,0 +1,199 @@
+"""The reference's own entry points (drop-in modules) on the GPU, driven exactly
+like the reference's driver code and compared with the reference-generated
+golden runs (same numpy seed -> same trajectory)."""
+import itertools
+import os
+import pickle
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle as CO      # noqa: E402
+from oracle import kmc_oracle as O     # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+RTOL = 1e-12
+
+
+@pytest.fixture(scope='module')
+def tabs():
+    return np.load(os.path.join(GOLDEN, 'tables.npz'))
+
+
+@pytest.fixture(scope='module')
+def normcons_pickle(tabs, tmp_path_factory):
+    """A normcons_dictionary.p look-alike (protocol 2, str keys) built from the fixture."""
+    from kmc_amd import tables
+    d = {tables.base_key16(i): float(tabs['base512_normcons'][i]) for i in range(512)}
+    p = tmp_path_factory.mktemp('tables') / 'normcons_dictionary.p'
+    with open(p, 'wb') as f:
+        pickle.dump(d, f, protocol=2)
+    return str(p)
+
+
+@pytest.fixture(scope='module')
+def master_pickle(tabs, tmp_path_factory):
+    d = {int(k): float(v) for k, v in zip(tabs['master_keys'], tabs['master_values'])}
+    p = tmp_path_factory.mktemp('tables') / 'master_dictionary.p'
+    with open(p, 'wb') as f:
+        pickle.dump(d, f, protocol=2)
+    return str(p)
+
+
+@pytest.mark.parametrize('name', ['n10_x05', 'n10_x08', 'n8x12_x05', 'n30_x05'])
+def test_functional_dropin_replays_reference_run(name, normcons_pickle):
+    import kmc_amd.hex_LiCoO2_kmc as K
+    g = np.load(os.path.join(GOLDEN, 'traj_%s.npz' % name))
+    nx, ny, conc = int(g['nx']), int(g['ny']), float(g['conc'])
+    K.window_mode = 'hex_ref'
+    K.set_rate_table(normcons_pickle)
+    K.mc_lattice_size = [nx, ny, 1]
+    K.Li_concentration = conc
+    K.hop_histogram[:] = 0
+    size = K.mc_lattice_size
+    # ---- the reference's driver, hex_LiCoO2_kmc.py:695-768, verbatim in structure
+    np.random.seed(int(g['seed']))
+    hop_probability_matrix = np.tile(np.zeros(6), (size[0], size[1], size[2], 1))
+    distance_lattice = np.tile([-1, 0, 0], (size[0], size[1], size[2], 1))
+    mc_lattice = np.zeros(size) + np.float32(K.atom_types[1][1])
+    Li_atoms = 0
+    while Li_atoms <= conc * nx * ny - 1:
+        i = np.random.randint(0, size[0])
+        j = np.random.randint(0, size[1])
+        k = np.random.randint(0, size[2])
+        if mc_lattice[i][j][k] == K.atom_types[1][1]:
+            mc_lattice[i][j][k] = np.float32(K.atom_types[1][0])
+            Li_atoms += 1
+    K.mc_lattice = mc_lattice
+    hop_probability_matrix = K.kmc_evolve(mc_lattice, hop_probability_matrix, 0, 0, True)
+    assert np.array_equal(hop_probability_matrix[:, :, 0, :], g['P0'])
+    for _ in range(int(g['n_presim'])):
+        (mc_lattice, hop_probability_matrix) = K.kmc_step(mc_lattice, distance_lattice, hop_probability_matrix, True)
+    for i, j, k in itertools.product(range(size[0]), range(size[1]), range(size[2])):
+        distance_lattice[i][j][k] = list([i, j, k]) if mc_lattice[i][j][k] == K.atom_types[1][0] else [-1, 0, 0]
+    total_time = 0
+    steps = []
+    for _ in range(int(g['n_sim'])):
+        (mc_lattice, distance_lattice, time_step, hop_probability_matrix, hop_histogram, chosen_barrier) = \
+            K.kmc_step(mc_lattice, distance_lattice, hop_probability_matrix, False)
+        total_time = total_time + time_step
+        steps.append(time_step)
+    (d_star, lst, d_j) = K.get_diffusion_coefficient(distance_lattice, size, total_time, K.lattice_constant, conc)
+    # ---- against the reference's own outputs
+    assert np.array_equal((mc_lattice[:, :, 0] == -1).astype(np.uint8), g['occ_final'])
+    assert K.mc_lattice is mc_lattice                      # updated in place and returned
+    assert np.array_equal(distance_lattice[:, :, 0, :], g['tags_final'])
+    assert np.array_equal(hop_probability_matrix[:, :, 0, :], g['P_final'])
+    assert np.array_equal(hop_histogram, g['hist']) and hop_histogram is K.hop_histogram
+    np.testing.assert_allclose(steps, g['step_times'], rtol=RTOL)
+    np.testing.assert_allclose(d_star, float(g['d_star']), rtol=RTOL)
+    np.testing.assert_allclose(d_j, float(g['d_j']), rtol=RTOL)
+    np.testing.assert_allclose(chosen_barrier, g['barriers'][-1], rtol=1e-6)
+    mat, lst2, dj_len = K.get_distance(distance_lattice, size, K.lattice_constant)
+    assert np.array_equal(mat[:, :, 0], g['dist_matrix'])
+    assert np.array_equal(lst2, g['dist_list']) and np.array_equal(lst, g['dist_list'])
+    assert dj_len == float(g['dj_len'])
+    # get_hex_probability reads the module-global lattice (hex_LiCoO2_kmc.py:422-428)
+    dense = O.build_hex_table(np.load(os.path.join(GOLDEN, 'tables.npz'))['base512_normcons'])
+    occ = g['occ_final']
+    for (i, j) in [(0, 0), (nx - 1, ny - 1), (3, 5)]:
+        assert np.array_equal(K.get_hex_probability([i, j, 0]), dense[O.site_key(occ, i, j)])
+    K.close()
+
+
+def test_functional_kmc_evolve_window(normcons_pickle, tabs):
+    """Windowed kmc_evolve touches the reference's window only and keeps stale rows."""
+    import kmc_amd.hex_LiCoO2_kmc as K
+    K.window_mode = 'hex_ref'
+    K.set_rate_table(normcons_pickle)
+    dense = O.build_hex_table(tabs['base512_normcons'])
+    rs = np.random.RandomState(3)
+    nx, ny = 12, 10
+    occ = (rs.rand(nx, ny) < 0.5).astype(np.uint8)
+    occ[4, 4], occ[5, 4] = 1, 0
+    lat = np.where(occ == 1, -1.0, 1.0).reshape(nx, ny, 1)
+    K.mc_lattice_size = [nx, ny, 1]
+    K.mc_lattice = lat
+    P = K.kmc_evolve(lat, np.zeros((nx, ny, 1, 6)), 0, 0, True)
+    P_ref = O.rates_full(occ, dense)
+    assert np.array_equal(P[:, :, 0, :], P_ref)
+    lat[4, 4, 0], lat[5, 4, 0] = 1.0, -1.0
+    occ[4, 4], occ[5, 4] = 0, 1
+    out = K.kmc_evolve(lat, P, [4, 4, 0], [5, 4, 0], False)
+    assert out is P
+    O.rates_window(occ, P_ref, dense, (4, 4), (5, 4), 'hex_ref')
+    assert np.array_equal(P[:, :, 0, :], P_ref)
+    assert np.any(P_ref != O.rates_full(occ, dense))       # the window left stale sites behind
+    K.close()
+
+
+def test_master_dictionary_table(master_pickle, tabs):
+    """master_dictionary.p (int keys of 1/3) is accepted and restricted to 512 keys."""
+    import kmc_amd.hex_LiCoO2_kmc as K
+    K.set_rate_table(master_pickle)
+    assert np.array_equal(K.hex_table(), O.build_hex_table(tabs['base512_master']))
+    K.close()
+
+
+def test_dictionary_builder(tabs, tmp_path):
+    import kmc_amd.hex_LiCoO2_kmc as K
+    from kmc_amd import tables
+    p = tmp_path / 'normcons_dictionary.p'
+    d = K.dictionary_builder(str(p))
+    assert len(d) == 512
+    np.testing.assert_allclose(tables.base512_from_dict(tables.load_table_pickle(str(p))),
+                               tabs['base512_normcons'], rtol=RTOL)
+
+
+def test_mc_lattice_class(tabs):
+    """OO API: fill -> presim KMC_steps -> initialize_KMC -> KMC_steps -> D's,
+    against the C oracle with the class's own 5x6 window and the same draws."""
+    from kmc_amd.Mc_Lattice import mc_lattice
+    dense = O.build_hex_table(tabs['base512_normcons'])
+    mc_lattice.set_rate_table(tabs['base512_normcons'])
+    N, c = 20, 0.3
+    np.random.seed(4)
+    random.seed(9)
+    x = mc_lattice([N, N, 1])
+    x.fill_lattice(c)
+    assert x.number_of_li == int(c * N * N)
+    lat0 = x.lattice
+    assert lat0.shape == (N, N, 1) and set(np.unique(lat0)) == {'0', '1'}
+    occ0 = (lat0[:, :, 0] == '1').astype(np.uint8)
+    assert occ0.sum() == x.number_of_li
+    assert np.array_equal(x.probability_matrix[:, :, 0, :], O.rates_full(occ0, dense))
+    for _ in range(2):
+        x.KMC_step()
+    x.initialize_KMC()
+    for _ in range(3):
+        x.KMC_step()
+    x.hop()
+    x.calculate_diffusion_coefficients()
+    # replay with the oracle
+    random.seed(9)
+    n_li = x.number_of_li
+    d_pre = np.array([[random.random(), 1.0] for _ in range(2 * n_li)])
+    d_sim = np.array([[random.random(), random.random()] for _ in range(3 * n_li + 1)])
+    rep = CO.Replica(occ0, dense, 'obj_ref')
+    rep.run(d_pre, True)
+    rep.init_tags()
+    rep.run(d_sim, False)
+    assert np.array_equal((x.lattice[:, :, 0] == '1').astype(np.uint8), rep.occ)
+    assert np.array_equal(x.distance_lattice[:, :, 0, :], rep.tags)
+    assert np.array_equal(x.probability_matrix[:, :, 0, :], rep.P)
+    assert np.array_equal(x.hop_histogram, rep.hist)
+    np.testing.assert_allclose(x.total_time, rep.time.value, rtol=RTOL)
+    out = rep.diffusion(n_li / float(N * N))
+    a2 = x.lattice_constant ** 2
+    np.testing.assert_allclose(x.d_star, a2 * out[2] / (4 * rep.time.value * n_li), rtol=RTOL)
+    np.testing.assert_allclose(x.d_j, a2 * out[3] / (4 * rep.time.value * n_li), rtol=RTOL)
+    x.functional_normalisation = True
+    x.calculate_diffusion_coefficients()
+    np.testing.assert_allclose(x.d_star, out[0], rtol=RTOL)
+    np.testing.assert_allclose(x.d_j, out[1], rtol=RTOL)
+    assert np.array_equal(x.get_hex_probability([0, 0, 0]),
+                          dense[O.site_key(rep.occ, 0, 0)] if rep.occ[0, 0] else np.zeros(6))
+    x.close()
