@@ -14,6 +14,7 @@
 #include "../../include/kmc_hip.h"
 #include "kmc_device.h"
 #include "kmc_hop_lds.h"
+#include "kmc_hop_global.h"
 
 using namespace kmc;
 
@@ -46,6 +47,7 @@ struct kmc_ctx {
     int* status;
     double* barrier;
     double* scratch_d;     // [R*8] small per-replica scratch
+    double* w_g;           // [R][n] per-site rate sums, global-memory hop kernel only (lazy)
     // per-call staging
     double* draws; size_t draws_cap;
     int32_t* sel; size_t sel_cap;
@@ -447,6 +449,9 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     if (c->lds_path) {
         const size_t lds = host_hop_lds_bytes(c->n);
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else if (nx <= 4096) {
+        const size_t lds = ((sizeof(GbShared) + 15) & ~(size_t)15) + (size_t)nx * 8;
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_global_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     CREATE_CHK(hipStreamSynchronize(c->stream));
 #undef CREATE_CHK
@@ -462,7 +467,7 @@ int kmc_destroy(kmc_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* bufs[] = {c->occ, c->keys, c->tags, c->table, c->wsum, c->time_total, c->step_time, c->gamma, c->hist,
-                    c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel};
+                    c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel, c->w_g};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -768,7 +773,8 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     if (n_hops < 0) return fail(c, KMC_EINVAL, "kmc_run: n_hops < 0");
     if (!c->have_table) return fail(c, KMC_ESTATE, "kmc_run: set a rate table first");
     if (!c->have_keys) return fail(c, KMC_ESTATE, "kmc_run: run kmc_rates_full (or kmc_set_keys) first");
-    if (!c->lds_path) return fail(c, KMC_EINVAL, "kmc_run: lattices beyond 64 x 64 are not served yet (nx=%d, ny=%d)", c->nx, c->ny);
+    if (!c->lds_path && c->nx > 4096)
+        return fail(c, KMC_EINVAL, "kmc_run: nx = %d exceeds the 4096 rows the global-memory hop kernel keeps in LDS", c->nx);
     if (n_hops == 0) return KMC_OK;
     const size_t Rh = (size_t)c->R * (size_t)n_hops;
     if (draws) {
@@ -794,12 +800,41 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         HIPCHK(c, hipMemcpyAsync(dcounts, counts, (size_t)c->R * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    const double mfac = (6.0 * c->n + 256.0) * ldexp(1.0, -53) * 1.001 * c->margin_scale;
+    if (!c->lds_path) {
+        if (!c->w_g) HIPCHK(c, hipMalloc((void**)&c->w_g, (size_t)c->R * c->n * 8));
+        HopGlobalParams g;
+        memset(&g, 0, sizeof(g));
+        g.nx = c->nx; g.ny = c->ny; g.n = c->n; g.window_mode = c->window_mode;
+        g.n_hops = n_hops; g.n_hops_r = dcounts; g.presim = presim != 0; g.force_exact = c->force_exact;
+        g.mfac = mfac;
+        g.table = c->table; g.wsum = c->wsum; g.occ = c->occ; g.keys = c->keys; g.w = c->w_g; g.tags = c->tags;
+        g.draws = draws ? c->draws : nullptr; g.sel = sel_out ? c->sel : nullptr;
+        g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32);
+        g.time_total = c->time_total; g.step_time = c->step_time; g.gamma = c->gamma; g.hist = c->hist;
+        g.hops_done = c->hops_done; g.n_exact = c->n_exact; g.status = c->status; g.barrier = c->barrier;
+        const size_t lds = ((sizeof(GbShared) + 15) & ~(size_t)15) + (size_t)c->nx * 8;
+        const int slot = (int)(c->run_launches % KMC_EV_RING);
+        time_begin(c);
+        HIPCHK(c, hipEventRecord(c->run_ev[slot][0], c->stream));
+        hop_global_kernel<<<c->R, KMC_GB_THREADS, lds, c->stream>>>(g);
+        HIPCHK(c, hipEventRecord(c->run_ev[slot][1], c->stream));
+        time_end(c);
+        ++c->run_launches;
+        HIPCHK(c, hipGetLastError());
+        if (sel_out) {
+            HIPCHK(c, hipMemcpyAsync(sel_out, c->sel, Rh * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        if (draws) HIPCHK(c, hipStreamSynchronize(c->stream));
+        return KMC_OK;
+    }
     HopParams p;
     memset(&p, 0, sizeof(p));
     p.nx = c->nx; p.ny = c->ny; p.n = c->n; p.window_mode = c->window_mode;
     p.n_hops = n_hops; p.n_hops_r = dcounts; p.presim = presim != 0; p.force_exact = c->force_exact;
     // rigorous rounding bound of the certified selection, see kmc_hop_lds.h / DESIGN.md
-    p.mfac = (6.0 * c->n + 256.0) * ldexp(1.0, -53) * 1.001 * c->margin_scale;
+    p.mfac = mfac;
     p.table = c->table; p.wsum = c->wsum; p.occ = c->occ; p.keys = c->keys; p.tags = c->tags;
     p.draws = draws ? c->draws : nullptr; p.sel = sel_out ? c->sel : nullptr;
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);

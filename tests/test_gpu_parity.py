@@ -338,3 +338,87 @@ def test_errors_are_loud(kmc, tables):
         kmc.KMCEngine(1, 2)
     with pytest.raises(kmc.KMCError, match='device'):
         kmc.KMCEngine(1, 10, device=99)
+
+
+# ---------------------------------------------------------------- lattices beyond 64 x 64
+@pytest.mark.parametrize('cfg', [
+    # nx, ny, R, hops_pre, hops_sim, mode, force_exact, margin_scale
+    (65, 65, 3, 300, 900, 'hex_ref', False, 1.0),
+    (100, 37, 3, 300, 900, 'hex_ref', False, 1.0),
+    (37, 100, 2, 200, 600, 'full', False, 1.0),
+    (130, 70, 2, 200, 800, 'obj_ref', False, 1.0),
+    (300, 260, 2, 200, 800, 'hex_ref', False, 1.0),
+    (70, 66, 2, 40, 120, 'hex_ref', True, 1.0),
+    (90, 90, 2, 200, 600, 'hex_ref', False, 2e6),
+], ids=lambda c: '%dx%d-%s%s-m%g' % (c[0], c[1], c[5], '-exact' if c[6] else '', c[7]))
+def test_global_memory_kernel_vs_oracle(kmc, tables, dense, cfg):
+    nx, ny, R, hp, hs, mode, force, mscale = cfg
+    rs = np.random.RandomState(nx + ny)
+    conc = np.linspace(0.3, 0.7, R)
+    occ = np.stack([(rs.rand(nx, ny) < c).astype(np.int8) for c in conc])
+    d_pre = np.stack([rs.rand(R, hp), np.ones((R, hp))], axis=-1)
+    d_sim = rs.rand(R, hs, 2)
+    with make_engine(kmc, tables, R, nx, ny, mode) as eng:
+        assert not eng.uses_lds_path
+        eng.set_debug(force_exact=force, margin_scale=mscale)
+        eng.set_lattice(occ)
+        eng.rates_full()
+        i1 = eng.run(hp, presim=True, draws=d_pre, want_trace=True)
+        eng.init_displacements()
+        i2 = eng.run(hs, presim=False, draws=d_sim, want_trace=True)
+        got_idx = np.concatenate([i1, i2], axis=1)
+        lat, tags, P, sc, st = eng.get_lattice(), eng.get_reference_tags(), eng.get_rates(), eng.scalars(), eng.status()
+        ds, dj, _ = eng.diffusion(occ.reshape(R, -1).mean(axis=1))
+    for r in range(R):
+        rep, idx = _oracle_run(occ[r], dense, mode, d_pre[r], d_sim[r], conc[r])
+        assert np.array_equal(got_idx[r], idx), 'replica %d' % r
+        assert np.array_equal(lat[r], rep.occ) and np.array_equal(tags[r], rep.tags)
+        assert np.array_equal(P[r], rep.P)
+        assert np.array_equal(sc['hist'][r], rep.hist.astype(np.int64))
+        np.testing.assert_allclose(sc['time'][r], rep.time.value, rtol=RTOL)
+        np.testing.assert_allclose(sc['gamma'][r], np.sum(rep.P), rtol=RTOL)
+        out = rep.diffusion(float(occ[r].mean()))
+        np.testing.assert_allclose(ds[r], out[0], rtol=RTOL)
+    assert not st['status'].any()
+    if force:
+        assert (st['n_exact'] == hp + hs).all()
+    elif mscale > 1:
+        assert 0 < st['n_exact'].sum() < 0.5 * R * (hp + hs)
+
+
+def test_large_lattice_1024(kmc, tables, dense):
+    """BASELINE config 4: one 1024 x 1024 lattice.  Hop-for-hop against the C oracle
+    on a short run, then size-independent invariants on a longer Philox run."""
+    nx = 1024
+    rs = np.random.RandomState(1024)
+    occ = (rs.rand(1, nx, nx) < 0.5).astype(np.int8)
+    d_sim = rs.rand(1, 150, 2)
+    with make_engine(kmc, tables, 1, nx) as eng:
+        eng.set_lattice(occ)
+        eng.rates_full()
+        eng.init_displacements()
+        idx = eng.run(150, presim=False, draws=d_sim, want_trace=True)
+        rep = CO.Replica(occ[0], dense)
+        rep.init_tags()
+        _, ref_idx, _ = rep.run(d_sim[0], False)
+        assert np.array_equal(idx[0], ref_idx)
+        assert np.array_equal(eng.get_lattice()[0], rep.occ)
+        assert np.array_equal(eng.get_keys()[0], rep.keys)
+        np.testing.assert_allclose(eng.scalars()['time'][0], rep.time.value, rtol=RTOL)
+        # longer production-mode run: particle number conserved, every hop moved one
+        # atom by one lattice vector, the rate state is reproducible from the keys
+        n_li = int(occ.sum())
+        eng.run(20000, presim=False, seed=7)
+        lat = eng.get_lattice()[0]
+        assert int(lat.sum()) == n_li
+        tags = eng.get_displacements()[0]
+        assert int((tags[..., 0] >= 0).sum()) == n_li and np.array_equal(tags[..., 0] >= 0, lat == 1)
+        st = eng.status()
+        assert st['status'][0] == 0 and st['hops_done'][0] == 20150
+        assert eng.scalars()['hist'][0].sum() == 20150
+        keys = eng.get_keys()[0]
+        fresh = O.all_keys(lat)
+        assert np.array_equal(keys == 0xFFFFFFFF, fresh == 0xFFFFFFFF)      # vacancy pattern always fresh
+        assert (keys != fresh).mean() < 0.2                                  # stale keys exist but are a minority
+        g = eng.gamma_exact()[0]
+        np.testing.assert_allclose(eng.scalars()['gamma'][0], g, rtol=RTOL)
