@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
                 rho_v = u53(o.x, o.y); u_v = u53_open0(o.z, o.w);
             }
         }
-        double gam_v = 1.0, pn_v = 1.0;    // per-lane record of hop (h0 + lane)
+        double gam_v = 1.0, pn_v = 1.0, pd_v = 1.0;    // per-lane record of hop (h0 + lane)
         int idx_v = -1;
 
         int hl = 0;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
             const double t = rho * gamma;
             const double M = gamma * p.mfac;
             int i = 0, j = 0, d = 0;
-            double lo = 0.0, hi = 0.0, pnorm = 0.0;
+            double lo = 0.0, hi = 0.0, pnum = 1.0, pden = 1.0;   // chosen rate / gamma, divided at the flush
             bool ok = (gamma > 0.0) && !p.force_exact;
             // ---- row ------------------------------------------------------
             if (ok) {
@@ -192,16 +192,17 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
                 ok = k != KMC_VACANT;
                 if (ok) {
                     const cdouble_ptr tr = ctable + (size_t)k * 6;
-                    double c = sitebase;
-                    bool found = false;
-#pragma unroll
-                    for (int dd = 0; dd < 6; ++dd) {
-                        const double rate = tr[dd];
-                        const double cn = c + rate;
-                        if (!found && cn >= t) { found = true; d = dd; lo = c; hi = cn; pnorm = rate / gamma; }
-                        c = cn;
-                    }
-                    ok = found && (hi - t >= M) && (t - lo >= M);
+                    const double r0 = tr[0], r1 = tr[1], r2 = tr[2], r3 = tr[3], r4 = tr[4], r5 = tr[5];
+                    const double c0 = sitebase + r0, c1 = c0 + r1, c2 = c1 + r2, c3 = c2 + r3, c4 = c3 + r4,
+                                 c5 = c4 + r5;
+                    // running sums are non-decreasing: the first one reaching t is counted by the misses
+                    d = (c0 < t) + (c1 < t) + (c2 < t) + (c3 < t) + (c4 < t) + (c5 < t);
+                    ok = d < 6;
+                    lo = d == 0 ? sitebase : d == 1 ? c0 : d == 2 ? c1 : d == 3 ? c2 : d == 4 ? c3 : c4;
+                    hi = d == 0 ? c0 : d == 1 ? c1 : d == 2 ? c2 : d == 3 ? c3 : d == 4 ? c4 : c5;
+                    pnum = d == 0 ? r0 : d == 1 ? r1 : d == 2 ? r2 : d == 3 ? r3 : d == 4 ? r4 : r5;
+                    pden = gamma;
+                    ok = ok && (hi - t >= M) && (t - lo >= M);
                 }
             }
             if (!ok) {
@@ -217,7 +218,8 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
                 d = (int)(idx % 6);
                 j = (int)((idx / 6) % ny);
                 i = (int)((idx / 6) / ny);
-                pnorm = pick->c / g - pick->cprev / g;
+                pnum = pick->c / g - pick->cprev / g;      // the reference's own expression (:497)
+                pden = 1.0;
             }
             const int s_src = i * ny + j;
             const int idx = s_src * 6 + d;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
             if (lane == jw) cb |= (1ull << iw);
             if (lane == j || lane == jw) col[lane] = cb;
             if (lane == d) ++hist_v;
-            if (lane == hl) { gam_v = gamma; pn_v = pnorm; idx_v = idx; }
+            if (lane == hl) { gam_v = gamma; pn_v = pnum; pd_v = pden; idx_v = idx; }
             ++hops;
             wave_fence();
             // ---- windowed refresh (:444-465) --------------------------------------
@@ -245,18 +247,21 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
                 i_lo = (di < 0 ? ie : i) - 2; n_i = 5 + (di != 0);
                 j_lo = (dj < 0 ? je : j) - 2; n_j = 5 + (dj != 0);
             }
-            if (lane < n_i * n_j) {
-                const int a = lane / n_j, b = lane - a * n_j;
-                const int si = wrap1(i_lo + a, nx), sj = wrap1(j_lo + b, ny);
-                const int s = si * ny + sj;
-                uint32_t knew = KMC_VACANT;
-                double wnew = 0.0;
-                if ((col[sj] >> si) & 1ull) {
-                    knew = key_from_cols([&](int c) { return col[c]; }, nx, ny, si, sj);
-                    wnew = p.wsum[knew];
+            {
+                // lane = 8 * (window row) + (window column): no division by n_j
+                const int a = lane >> 3, b = lane & 7;
+                if (a < n_i && b < n_j) {
+                    const int si = wrap1(i_lo + a, nx), sj = wrap1(j_lo + b, ny);
+                    const int s = si * ny + sj;
+                    uint32_t knew = KMC_VACANT;
+                    double wnew = 0.0;
+                    if ((col[sj] >> si) & 1ull) {
+                        knew = key_from_cols([&](int c) { return col[c]; }, nx, ny, si, sj);
+                        wnew = p.wsum[knew];
+                    }
+                    key[s] = knew;
+                    w[s] = wnew;
                 }
-                key[s] = knew;
-                w[s] = wnew;
             }
             // ---- tag move, deferred by one hop (:521-528) ------------------------------
             if (!p.presim) {
@@ -275,11 +280,25 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
             }
             wave_fence();
             // ---- re-sum touched rows, re-scan -----------------------------------------
-            for (int a = 0; a < n_i; ++a) {
-                const int row = wrap1(i_lo + a, nx);
-                const double v = lane < ny ? w[row * ny + lane] : 0.0;
-                const double tot = wave_sum(v);
-                if (lane == row) rsum = tot;
+            {
+                // lane = 8 * (window row a) + c: sum every 8th site of that lattice row starting
+                // at c, then combine the eight partial sums inside the 8-lane group
+                const int a = lane >> 3, c = lane & 7;
+                const int row = wrap1(i_lo + (a < n_i ? a : 0), nx);
+                const int per = (ny + 7) >> 3;
+                const double* wr = w + row * ny;
+                double part = 0.0;
+                for (int q = 0; q < per; ++q) {
+                    const int jj = q * 8 + c;
+                    part += (jj < ny) ? wr[jj] : 0.0;
+                }
+                part += dpp_f64<0xB1, 0xF>(part);      // quad_perm [1,0,3,2]: + neighbour
+                part += dpp_f64<0x4E, 0xF>(part);      // quad_perm [2,3,0,1]: + other pair
+                part += dpp_f64<0x141, 0xF>(part);     // row_half_mirror: + other quad of the 8
+                for (int aa = 0; aa < n_i; ++aa) {
+                    const double tot = readlane_f64(part, aa * 8);
+                    if (lane == wrap1(i_lo + aa, nx)) rsum = tot;
+                }
             }
             rowpre = wave_scan_incl(rsum);
             gamma = readlane_f64(rowpre, 63);
@@ -293,7 +312,7 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
         if (p.sel && lane < cnt) p.sel[(size_t)r * p.n_hops + h0 + lane] = lane < done ? idx_v : -1;
         {
             const bool has = lane < done && idx_v != 0;                          // :495
-            const double bar = has ? -log(pn_v / 1e13) * 0.025 : 0.0;           // :496-498
+            const double bar = has ? -log((pn_v / pd_v) / 1e13) * 0.025 : 0.0;  // :496-498
             const unsigned long long m = __ballot(has);
             if (m) {
                 b_last = readlane_f64(bar, 63 - __builtin_clzll(m));
