@@ -55,6 +55,31 @@ __device__ __forceinline__ double wave_scan_incl(double x)
     return x;
 }
 
+// Inclusive prefix sum valid in lanes 0..7 only (lanes 8..15 also see lanes below them).
+__device__ __forceinline__ double scan8_incl(double x)
+{
+    x += dpp_f64<0x111, 0xF>(x);
+    x += dpp_f64<0x112, 0xF>(x);
+    x += dpp_f64<0x114, 0xF>(x);
+    return x;
+}
+
+// Sum over each aligned group of 8 lanes, association ((x0+x1)+(x2+x3))+((x4+x5)+(x6+x7));
+// every lane of the group receives the same bits (fp add is commutative).
+__device__ __forceinline__ double group8_sum(double x)
+{
+    x += dpp_f64<0xB1, 0xF>(x);      // quad_perm [1,0,3,2]
+    x += dpp_f64<0x4E, 0xF>(x);      // quad_perm [2,3,0,1]
+    x += dpp_f64<0x141, 0xF>(x);     // row_half_mirror
+    return x;
+}
+
+// Left-to-right sum of 8 consecutive doubles (a row's block sums).
+__device__ __forceinline__ double row_sum8(const double* b)
+{
+    return ((((((b[0] + b[1]) + b[2]) + b[3]) + b[4]) + b[5]) + b[6]) + b[7];
+}
+
 __device__ __forceinline__ double readlane_f64(double x, int lane)
 {
     int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);

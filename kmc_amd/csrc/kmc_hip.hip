@@ -379,9 +379,10 @@ static int dmalloc(kmc_ctx* c, T** p, size_t count)
     return 0;
 }
 
-static size_t host_hop_lds_bytes(int n)
+static size_t host_hop_lds_bytes(int nx, int n)
 {
-    return (size_t)8 * n + 512 + (((size_t)4 * n + 15) & ~(size_t)15) + sizeof(PwFrame) * KMC_PW_DEPTH + 64;
+    size_t a, b, c;
+    return hop_lds_layout(nx, n, &a, &b, &c);
 }
 
 extern "C" {
@@ -447,7 +448,7 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     CREATE_CHK(hipMemsetAsync(c->n_exact, 0, c->R * 8, c->stream));
     CREATE_CHK(hipMemsetAsync(c->status, 0, c->R * 4, c->stream));
     if (c->lds_path) {
-        const size_t lds = host_hop_lds_bytes(c->n);
+        const size_t lds = host_hop_lds_bytes(c->nx, c->n);
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (nx <= 4096) {
         const size_t lds = ((sizeof(GbShared) + 15) & ~(size_t)15) + (size_t)nx * 8;
@@ -510,7 +511,7 @@ int kmc_run_kernel_times(kmc_ctx* c, float* ms, int max_n, int* n_out)
 }
 
 int kmc_uses_lds_path(kmc_ctx* c) { return c && c->lds_path ? 1 : 0; }
-int kmc_lds_bytes(kmc_ctx* c) { return c && c->lds_path ? (int)host_hop_lds_bytes(c->n) : 0; }
+int kmc_lds_bytes(kmc_ctx* c) { return c && c->lds_path ? (int)host_hop_lds_bytes(c->nx, c->n) : 0; }
 
 // ---------------------------------------------------------------- tables
 int kmc_set_base_table(kmc_ctx* c, const double* base512, double dumbbell)
@@ -843,7 +844,7 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     const int slot = (int)(c->run_launches % KMC_EV_RING);
     time_begin(c);
     HIPCHK(c, hipEventRecord(c->run_ev[slot][0], c->stream));
-    hop_lds_kernel<<<c->R, 64, host_hop_lds_bytes(c->n), c->stream>>>(p);
+    hop_lds_kernel<<<c->R, 64, host_hop_lds_bytes(c->nx, c->n), c->stream>>>(p);
     HIPCHK(c, hipEventRecord(c->run_ev[slot][1], c->stream));
     time_end(c);
     ++c->run_launches;

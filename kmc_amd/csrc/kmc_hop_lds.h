@@ -1,26 +1,38 @@
 // kmc_hop_lds.h -- the fused, LDS-resident hop loop (rows S1-S5, U1-U4, R3, K).
 //
-// One wave64 = one replica.  A replica's whole selection state lives in LDS:
-//   w[n]    f64  sum of the six rates of each site (at its last refresh)
-//   key[n]  u32  18-bit key of each site at its last refresh (stale keys are
-//                state: the reference's window leaves 6-7 affected sites
-//                un-refreshed per hop)
-//   col[ny] u64  occupancy, one bitmap per lattice column (bit i = row i)
+// One wave64 = one replica = one workgroup.  Per replica in LDS (64 x 64: 21 KB,
+// so 7 replicas per CU instead of the 3 a per-site fp64 array would allow):
+//   key[n]   u32  18-bit key of each site at its last refresh (stale keys are
+//                 state: the reference's window leaves 6-7 affected sites
+//                 un-refreshed per hop)
+//   blk[nx*8] f64 sum of the rates of each block of 8 consecutive sites of a row
+//   col[ny]  u64  occupancy, one bitmap per lattice column (bit i = row i)
 // and in registers: lane i holds the sum of row i and its inclusive prefix.
+// Per-site rate sums are NOT stored: W[key] (2 MB, L2 resident) is gathered when
+// a site's weight is needed, T[key] (12.6 MB) when its six rates are.
 //
 // Per hop (hex_LiCoO2_kmc.py:484-535):
-//   t = rho * gamma                                   (:486-490)
-//   row    = first lane with rowprefix >= t           ballot on registers
-//   site   = first lane with rowbase + scan(w[row]) >= t   one LDS row + DPP scan
-//   dir    = first of the six table rates crossing t  scalar loads of T[key]
-//   certify: the reference picks the first idx with fl(cumsum_seq[idx]/np.sum) >= rho;
-//            our sums associate differently, so the pick is accepted only if t is
-//            further than a rigorous rounding bound M from both neighbouring
-//            boundaries; otherwise (about 3e-8 of hops at 64x64) the hop is
-//            re-evaluated by exact_select(), a literal sequential restatement.
-//   update bitmaps / tags / clock / histogram         (:518-535)
-//   refresh the <= 36 window sites (keys from bitmaps, gather Wsum[key]), re-sum
-//   the <= 6 touched rows, re-scan the row prefix     (:444-465)
+//   t = rho * gamma                                            (:486-490)
+//   row    first lane with rowprefix >= t                      ballot on registers
+//   block  first of the row's 8 block sums reaching t          8 LDS reads + DPP scan
+//   entry  the block's 8 sites x 6 directions = 48 lanes gather T[key][dir]
+//          (one L2 round trip), DPP scan, first lane reaching t -> site AND direction
+//   certify (below) or exact_select()
+//   update bitmaps / tags / clock / histogram                  (:518-535)
+//   refresh the <= 36 window sites: new keys from the bitmaps   (:444-465)
+//   re-sum the <= 18 blocks the window touches from W[key] (8 lanes per block, fixed
+//   tree), re-sum the <= 6 touched rows from their blocks, re-scan the row prefix.
+//   Every stored sum is a pure function of the keys: nothing is updated by
+//   differences, so nothing drifts.
+//
+// Exactness.  The reference picks the first idx with fl(cumsum_seq[idx]/np.sum) >= rho.
+// Our running sums associate differently, so the pick is accepted only if t is
+// further than a rigorous bound M from both neighbouring boundaries (lo, hi):
+//     M = gamma * (6n + 256) * 2^-53 * 1.001
+//   6n      rounding of the reference's sequential sum (k <= 6n terms)
+//   256     our own <= 40 roundings (5 per W, 3 per block, 7 per row, 6 + 3 + 6 in the
+//           scans), gamma vs np.sum, fl(rho*gamma), the 2u of fl(c/gamma) >= rho
+// Otherwise (about 3e-8 of hops at 64x64) exact_select() replays the reference.
 #pragma once
 #include "kmc_device.h"
 
@@ -31,7 +43,7 @@ struct HopParams {
     long long n_hops;            // hops per replica (stride of draws / sel)
     const long long* n_hops_r;   // [R] per-replica hop counts (<= n_hops) or null
     int presim, force_exact;
-    double mfac;                 // certification margin = gamma * mfac
+    double mfac;                 // (6n + 256) * 2^-53 * 1.001 * margin_scale
     const double* table;         // [2^18][6]
     const double* wsum;          // [2^18]
     uint8_t* occ;                // [R][n]
@@ -49,8 +61,6 @@ struct HopParams {
     int* status;                 // [R]
     double* barrier;             // [R][5] last, sum, min, max, count
 };
-
-typedef const __attribute__((address_space(4))) double* cdouble_ptr;
 
 // The workgroup is ONE wave: its LDS instructions execute in issue order, so a
 // cross-lane LDS hand-off needs no s_barrier and no s_waitcnt, only a point the
@@ -94,38 +104,58 @@ __device__ __noinline__ void exact_select(const uint32_t* key, const double* tab
     out->idx = idx; out->gamma = gamma; out->c = c; out->cprev = cprev;
 }
 
+#define KMC_LDS_FRAMES 16        // pairwise recursion depth for n6 <= 8192 per buffer is 7
+
+__host__ __device__ inline size_t hop_lds_layout(int nx, int n, size_t* off_blk, size_t* off_col, size_t* off_frames)
+{
+    size_t o = ((size_t)4 * n + 15) & ~(size_t)15;           // key
+    *off_blk = o; o += (size_t)nx * 8 * 8;                   // blk
+    *off_col = o; o += 64 * 8;                               // col
+    *off_frames = o; o += sizeof(PwFrame) * KMC_LDS_FRAMES + sizeof(ExactPick) + 16;
+    return o;
+}
+
 __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int r = blockIdx.x, lane = threadIdx.x;
     const int nx = p.nx, ny = p.ny, n = p.n;
-    double* w = reinterpret_cast<double*>(smem);
-    uint64_t* col = reinterpret_cast<uint64_t*>(smem + (size_t)8 * n);
-    uint32_t* key = reinterpret_cast<uint32_t*>(smem + (size_t)8 * n + 512);
-    PwFrame* frames = reinterpret_cast<PwFrame*>(smem + (size_t)8 * n + 512 + (((size_t)4 * n + 15) & ~(size_t)15));
-    ExactPick* pick = reinterpret_cast<ExactPick*>(frames + KMC_PW_DEPTH);
+    size_t off_blk, off_col, off_frames;
+    hop_lds_layout(nx, n, &off_blk, &off_col, &off_frames);
+    uint32_t* key = reinterpret_cast<uint32_t*>(smem);
+    double* blk = reinterpret_cast<double*>(smem + off_blk);
+    uint64_t* col = reinterpret_cast<uint64_t*>(smem + off_col);
+    PwFrame* frames = reinterpret_cast<PwFrame*>(smem + off_frames);
+    ExactPick* pick = reinterpret_cast<ExactPick*>(frames + KMC_LDS_FRAMES);
 
     uint8_t* occ_g = p.occ + (size_t)r * n;
     uint32_t* keys_g = p.keys + (size_t)r * n;
     int4* tags_g = p.tags + (size_t)r * n;
+    const double* __restrict__ wsum = p.wsum;
+    const double* __restrict__ table = p.table;
 
     // ---- load the replica ------------------------------------------------
     uint64_t cb = 0;                       // lane j owns column j's bitmap
     if (lane < ny)
         for (int i = 0; i < nx; ++i) cb |= (uint64_t)(occ_g[i * ny + lane] & 1u) << i;
     col[lane] = cb;
-    for (int s = lane; s < n; s += KMC_WAVE) {
-        const uint32_t k = keys_g[s];
-        key[s] = k;
-        w[s] = (k == KMC_VACANT) ? 0.0 : p.wsum[k];
-    }
-    __syncthreads();
-    double rsum = 0.0;                     // lane i owns the sum of row i
+    for (int s = lane; s < n; s += KMC_WAVE) key[s] = keys_g[s];
+    wave_fence();
+
+    // per-lane constants: lane = 8 * a + c (8-lane groups)
+    const int grp_a = lane >> 3, grp_c = lane & 7;
+    const int nb = (ny + 7) >> 3;                      // blocks of 8 sites per row
+    const int nslots = nb < ((ny & 7) ? 3 : 2) ? nb : ((ny & 7) ? 3 : 2);   // blocks a window row can touch
+
+    // Every block sum is the fixed tree ((w0+w1)+(w2+w3))+((w4+w5)+(w6+w7)) over 8 lanes,
+    // every row sum the left-to-right sum of its 8 block sums.
     for (int row = 0; row < nx; ++row) {
-        const double v = lane < ny ? w[row * ny + lane] : 0.0;
-        const double tot = wave_sum(v);
-        if (lane == row) rsum = tot;
+        const uint32_t k = lane < ny ? key[row * ny + lane] : KMC_VACANT;
+        const double bs = group8_sum(k == KMC_VACANT ? 0.0 : wsum[k]);
+        if (grp_c == 0) blk[row * 8 + grp_a] = bs;
     }
+    wave_fence();
+    double rsum = lane < nx ? row_sum8(blk + lane * 8) : 0.0;   // lane i owns the sum of row i
     double rowpre = wave_scan_incl(rsum);
     double gamma = readlane_f64(rowpre, 63);
 
@@ -135,12 +165,15 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
     double time_acc = 0.0;
     double b_last = p.barrier[r * 5 + 0], b_sum = 0.0, b_min = 1e300, b_max = -1e300, b_cnt = 0.0;
     const long long hop0 = p.hops_done[r];
-    const cdouble_ptr ctable = (cdouble_ptr)(uintptr_t)p.table;
 
     // deferred tag move (the load of one hop is consumed during the next)
     bool pend = false;
     int pend_src = 0, pend_dst = 0, pend_dwi = 0, pend_dwj = 0;
     int4 pend_tag = make_int4(0, 0, 0, 0);
+
+    // per-lane constants of the 48-lane entry pick: lane = 6 * (site in block) + direction
+    const int ent_site = (lane * 43) >> 8;             // lane / 6 for lane < 48
+    const int ent_dir = lane - 6 * ent_site;
 
     const long long my_hops = p.n_hops_r ? p.n_hops_r[r] : p.n_hops;
     for (long long h0 = 0; h0 < my_hops && status == 0; h0 += KMC_WAVE) {
@@ -167,7 +200,7 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
             const double t = rho * gamma;
             const double M = gamma * p.mfac;
             int i = 0, j = 0, d = 0;
-            double lo = 0.0, hi = 0.0, pnum = 1.0, pden = 1.0;   // chosen rate / gamma, divided at the flush
+            double pnum = 1.0, pden = 1.0;          // chosen rate / gamma, divided at the flush
             bool ok = (gamma > 0.0) && !p.force_exact;
             // ---- row ------------------------------------------------------
             if (ok) {
@@ -175,34 +208,37 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
                 ok = m != 0ull;
                 i = ok ? (__ffsll((long long)m) - 1) : 0;
             }
-            double rowbase = 0.0, sp = 0.0;
             if (ok) {
-                rowbase = i > 0 ? readlane_f64(rowpre, i - 1) : 0.0;
-                // ---- site ---------------------------------------------------
-                const double v = lane < ny ? w[i * ny + lane] : 0.0;
-                sp = wave_scan_incl(v);
-                const unsigned long long m = __ballot(rowbase + sp >= t && lane < ny);
-                ok = m != 0ull;
-                j = ok ? (__ffsll((long long)m) - 1) : 0;
-            }
-            if (ok) {
-                // ---- direction ----------------------------------------------
-                const double sitebase = rowbase + (j > 0 ? readlane_f64(sp, j - 1) : 0.0);
-                const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)key[i * ny + j]);
-                ok = k != KMC_VACANT;
+                const double rowbase = i > 0 ? readlane_f64(rowpre, i - 1) : 0.0;
+                // ---- block: lanes 0..7 hold the row's block sums ----------------------------
+                const double bv = lane < 8 ? blk[i * 8 + lane] : 0.0;
+                const double bp = rowbase + scan8_incl(bv);           // only lanes 0..7 are read
+                const unsigned long long mb = __ballot(bp >= t && lane < 8);
+                ok = mb != 0ull;
                 if (ok) {
-                    const cdouble_ptr tr = ctable + (size_t)k * 6;
-                    const double r0 = tr[0], r1 = tr[1], r2 = tr[2], r3 = tr[3], r4 = tr[4], r5 = tr[5];
-                    const double c0 = sitebase + r0, c1 = c0 + r1, c2 = c1 + r2, c3 = c2 + r3, c4 = c3 + r4,
-                                 c5 = c4 + r5;
-                    // running sums are non-decreasing: the first one reaching t is counted by the misses
-                    d = (c0 < t) + (c1 < t) + (c2 < t) + (c3 < t) + (c4 < t) + (c5 < t);
-                    ok = d < 6;
-                    lo = d == 0 ? sitebase : d == 1 ? c0 : d == 2 ? c1 : d == 3 ? c2 : d == 4 ? c3 : c4;
-                    hi = d == 0 ? c0 : d == 1 ? c1 : d == 2 ? c2 : d == 3 ? c3 : d == 4 ? c4 : c5;
-                    pnum = d == 0 ? r0 : d == 1 ? r1 : d == 2 ? r2 : d == 3 ? r3 : d == 4 ? r4 : r5;
-                    pden = gamma;
-                    ok = ok && (hi - t >= M) && (t - lo >= M);
+                    const int q = __ffsll((long long)mb) - 1;
+                    const double blockbase = q > 0 ? readlane_f64(bp, q - 1) : rowbase;
+                    // ---- entry: 8 sites x 6 directions on 48 lanes -------------------------
+                    const int js = q * 8 + ent_site;
+                    double rate = 0.0;
+                    if (lane < 48 && js < ny) {
+                        const uint32_t k = key[i * ny + js];
+                        if (k != KMC_VACANT) rate = table[(size_t)k * 6 + ent_dir];
+                    }
+                    const double ap = blockbase + wave_scan_incl(rate);
+                    const unsigned long long me = __ballot(ap >= t && lane < 48);
+                    ok = me != 0ull;
+                    if (ok) {
+                        const int el = __ffsll((long long)me) - 1;
+                        const double hi = readlane_f64(ap, el);
+                        const double lo = el > 0 ? readlane_f64(ap, el - 1) : blockbase;
+                        pnum = readlane_f64(rate, el);
+                        pden = gamma;
+                        const int es = (el * 43) >> 8;
+                        j = q * 8 + es;
+                        d = el - 6 * es;
+                        ok = (pnum > 0.0) && (hi - t >= M) && (t - lo >= M);
+                    }
                 }
             }
             if (!ok) {
@@ -247,22 +283,17 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
                 i_lo = (di < 0 ? ie : i) - 2; n_i = 5 + (di != 0);
                 j_lo = (dj < 0 ? je : j) - 2; n_j = 5 + (dj != 0);
             }
-            {
-                // lane = 8 * (window row) + (window column): no division by n_j
-                const int a = lane >> 3, b = lane & 7;
-                if (a < n_i && b < n_j) {
-                    const int si = wrap1(i_lo + a, nx), sj = wrap1(j_lo + b, ny);
-                    const int s = si * ny + sj;
-                    uint32_t knew = KMC_VACANT;
-                    double wnew = 0.0;
-                    if ((col[sj] >> si) & 1ull) {
-                        knew = key_from_cols([&](int c) { return col[c]; }, nx, ny, si, sj);
-                        wnew = p.wsum[knew];
-                    }
-                    key[s] = knew;
-                    w[s] = wnew;
-                }
+            if (n_i > nx) n_i = nx;
+            if (n_j > ny) n_j = ny;
+            // lane = 8 * (window row) + (window column)
+            const int si = wrap1(i_lo + (grp_a < n_i ? grp_a : 0), nx);      // this group's lattice row
+            if (grp_a < n_i && grp_c < n_j) {
+                const int sj = wrap1(j_lo + grp_c, ny);
+                uint32_t knew = KMC_VACANT;
+                if ((col[sj] >> si) & 1ull) knew = key_from_cols([&](int c) { return col[c]; }, nx, ny, si, sj);
+                key[si * ny + sj] = knew;
             }
+            wave_fence();
             // ---- tag move, deferred by one hop (:521-528) ------------------------------
             if (!p.presim) {
                 if (lane == 0) {
@@ -278,27 +309,38 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
                 pend_dwi = ie < 0 ? -1 : (ie >= nx ? 1 : 0);
                 pend_dwj = je < 0 ? -1 : (je >= ny ? 1 : 0);
             }
-            wave_fence();
-            // ---- re-sum touched rows, re-scan -----------------------------------------
+            // ---- re-sum the touched blocks and rows -------------------------------------
             {
-                // lane = 8 * (window row a) + c: sum every 8th site of that lattice row starting
-                // at c, then combine the eight partial sums inside the 8-lane group
-                const int a = lane >> 3, c = lane & 7;
-                const int row = wrap1(i_lo + (a < n_i ? a : 0), nx);
-                const int per = (ny + 7) >> 3;
-                const double* wr = w + row * ny;
-                double part = 0.0;
-                for (int q = 0; q < per; ++q) {
-                    const int jj = q * 8 + c;
-                    part += (jj < ny) ? wr[jj] : 0.0;
+                // a window row's <= 6 columns lie in at most two consecutive blocks of 8 sites
+                // (three when the row's last block is partial and the window wraps past it);
+                // group a re-sums those blocks of its row, lane c taking site c of each
+                const int b0 = wrap1(j_lo, ny) >> 3;                   // block of window column 0
+                const bool act = grp_a < n_i;
+                const uint32_t* krow = key + si * ny;
+                auto site_w = [&](int bg) -> double {
+                    const int cj = bg * 8 + grp_c;
+                    const uint32_t k = (act && cj < ny) ? krow[cj] : KMC_VACANT;
+                    return k == KMC_VACANT ? 0.0 : wsum[k];
+                };
+                int b1 = b0 + 1; if (b1 >= nb) b1 -= nb;
+                int b2 = b1 + 1; if (b2 >= nb) b2 -= nb;
+                const double w0 = site_w(b0);
+                const double w1 = nslots > 1 ? site_w(b1) : 0.0;
+                const double w2 = nslots > 2 ? site_w(b2) : 0.0;
+                const double s0 = group8_sum(w0);
+                if (act && grp_c == 0) blk[si * 8 + b0] = s0;
+                if (nslots > 1) {
+                    const double s1 = group8_sum(w1);
+                    if (act && grp_c == 1) blk[si * 8 + b1] = s1;
                 }
-                part += dpp_f64<0xB1, 0xF>(part);      // quad_perm [1,0,3,2]: + neighbour
-                part += dpp_f64<0x4E, 0xF>(part);      // quad_perm [2,3,0,1]: + other pair
-                part += dpp_f64<0x141, 0xF>(part);     // row_half_mirror: + other quad of the 8
-                for (int aa = 0; aa < n_i; ++aa) {
-                    const double tot = readlane_f64(part, aa * 8);
-                    if (lane == wrap1(i_lo + aa, nx)) rsum = tot;
+                if (nslots > 2) {
+                    const double s2 = group8_sum(w2);
+                    if (act && grp_c == 2) blk[si * 8 + b2] = s2;
                 }
+                wave_fence();
+                int rel = lane - wrap1(i_lo, nx);
+                if (rel < 0) rel += nx;
+                if (rel < n_i && lane < nx) rsum = row_sum8(blk + lane * 8);
             }
             rowpre = wave_scan_incl(rsum);
             gamma = readlane_f64(rowpre, 63);
