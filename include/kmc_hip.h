@@ -152,6 +152,12 @@ int kmc_get_distances(kmc_ctx* ctx, double lattice_constant, double* matrix /* [
 int kmc_uses_lds_path(kmc_ctx* ctx);
 /* dynamic LDS bytes per replica of the hop kernel */
 int kmc_lds_bytes(kmc_ctx* ctx);
+/* 64 x 64 replicas run a kernel specialised for that size (kmc_hop_lds64.h); generic != 0 selects the
+ * any-size LDS kernel instead (tests compare the two).  No counterpart in the reference. */
+int kmc_set_hop_kernel(kmc_ctx* ctx, int generic);
+/* profiling builds only (-DKMC_STAMPS): cycles [R][8] the last kmc_run spent per hop segment, measured
+ * with s_memtime; any other build returns KMC_ESTATE.  No counterpart in the reference. */
+int kmc_debug_stamps(kmc_ctx* ctx, int64_t* out);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libkmc_hip.so')
+# KMC_AMD_LIB selects another build of the same library (profiling builds, scripts/stamps.py)
+LIB_PATH = os.environ.get('KMC_AMD_LIB') or os.path.join(HERE, 'libkmc_hip.so')
 
 # name -> (restype, argtypes); mirrors include/kmc_hip.h one to one
 _ctx = C.c_void_p
@@ -54,6 +55,8 @@ SIGNATURES = {
     'kmc_get_distances': (C.c_int, [_ctx, C.c_double, _dp]),
     'kmc_uses_lds_path': (C.c_int, [_ctx]),
     'kmc_lds_bytes': (C.c_int, [_ctx]),
+    'kmc_set_hop_kernel': (C.c_int, [_ctx, C.c_int]),
+    'kmc_debug_stamps': (C.c_int, [_ctx, _i64p]),
 }
 
 _lib = None

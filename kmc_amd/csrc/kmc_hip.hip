@@ -14,6 +14,7 @@
 #include "../../include/kmc_hip.h"
 #include "kmc_device.h"
 #include "kmc_hop_lds.h"
+#include "kmc_hop_lds64.h"
 #include "kmc_hop_global.h"
 
 using namespace kmc;
@@ -27,6 +28,7 @@ using namespace kmc;
 struct kmc_ctx {
     int device, R, nx, ny, n, window_mode;
     bool lds_path;
+    bool lds64;            // 64 x 64 replicas: the specialised kernel of kmc_hop_lds64.h
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     bool timed;
@@ -426,8 +428,11 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     CREATE_CHK(hipMalloc((void**)&c->occ, Rn + 16));
     CREATE_CHK(hipMalloc((void**)&c->keys, Rn * 4 + 16));
     CREATE_CHK(hipMalloc((void**)&c->tags, Rn * 16 + 16));
-    CREATE_CHK(hipMalloc((void**)&c->table, (size_t)KMC_TABLE_ROWS * 6 * 8));
-    CREATE_CHK(hipMalloc((void**)&c->wsum, (size_t)KMC_TABLE_ROWS * 8));
+    // one extra all-zero row (index 2^18): the key of a vacant site inside hop_lds64_kernel
+    CREATE_CHK(hipMalloc((void**)&c->table, (size_t)(KMC_TABLE_ROWS + 1) * 6 * 8));
+    CREATE_CHK(hipMalloc((void**)&c->wsum, (size_t)(KMC_TABLE_ROWS + 1) * 8));
+    CREATE_CHK(hipMemsetAsync(c->table + (size_t)KMC_TABLE_ROWS * 6, 0, 48, c->stream));
+    CREATE_CHK(hipMemsetAsync(c->wsum + KMC_TABLE_ROWS, 0, 8, c->stream));
     CREATE_CHK(hipMalloc((void**)&c->time_total, c->R * 8));
     CREATE_CHK(hipMalloc((void**)&c->step_time, c->R * 8));
     CREATE_CHK(hipMalloc((void**)&c->gamma, c->R * 8));
@@ -447,7 +452,9 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     CREATE_CHK(hipMemsetAsync(c->hops_done, 0, c->R * 8, c->stream));
     CREATE_CHK(hipMemsetAsync(c->n_exact, 0, c->R * 8, c->stream));
     CREATE_CHK(hipMemsetAsync(c->status, 0, c->R * 4, c->stream));
+    c->lds64 = c->lds_path && nx == 64 && ny == 64;
     if (c->lds_path) {
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, K64_LDS_BYTES));
         const size_t lds = host_hop_lds_bytes(c->nx, c->n);
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (nx <= 4096) {
@@ -511,7 +518,18 @@ int kmc_run_kernel_times(kmc_ctx* c, float* ms, int max_n, int* n_out)
 }
 
 int kmc_uses_lds_path(kmc_ctx* c) { return c && c->lds_path ? 1 : 0; }
-int kmc_lds_bytes(kmc_ctx* c) { return c && c->lds_path ? (int)host_hop_lds_bytes(c->nx, c->n) : 0; }
+int kmc_lds_bytes(kmc_ctx* c)
+{
+    if (!c || !c->lds_path) return 0;
+    return c->lds64 ? K64_LDS_BYTES : (int)host_hop_lds_bytes(c->nx, c->n);
+}
+
+int kmc_set_hop_kernel(kmc_ctx* c, int generic)
+{
+    CTXCHK(c);
+    c->lds64 = c->lds_path && c->nx == 64 && c->ny == 64 && !generic;
+    return KMC_OK;
+}
 
 // ---------------------------------------------------------------- tables
 int kmc_set_base_table(kmc_ctx* c, const double* base512, double dumbbell)
@@ -841,10 +859,16 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
     p.time_total = c->time_total; p.step_time = c->step_time; p.gamma = c->gamma; p.hist = c->hist;
     p.hops_done = c->hops_done; p.n_exact = c->n_exact; p.status = c->status; p.barrier = c->barrier;
+#ifdef KMC_STAMPS
+    p.stamps = dcounts ? nullptr : reinterpret_cast<long long*>(c->scratch_d);
+#endif
     const int slot = (int)(c->run_launches % KMC_EV_RING);
     time_begin(c);
     HIPCHK(c, hipEventRecord(c->run_ev[slot][0], c->stream));
-    hop_lds_kernel<<<c->R, 64, host_hop_lds_bytes(c->nx, c->n), c->stream>>>(p);
+    if (c->lds64)
+        hop_lds64_kernel<<<c->R, 64, K64_LDS_BYTES, c->stream>>>(p);
+    else
+        hop_lds_kernel<<<c->R, 64, host_hop_lds_bytes(c->nx, c->n), c->stream>>>(p);
     HIPCHK(c, hipEventRecord(c->run_ev[slot][1], c->stream));
     time_end(c);
     ++c->run_launches;
@@ -855,6 +879,19 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     }
     if (draws) HIPCHK(c, hipStreamSynchronize(c->stream));   // the caller may reuse its buffer
     return KMC_OK;
+}
+
+int kmc_debug_stamps(kmc_ctx* c, int64_t* out)
+{
+    CTXCHK(c);
+#ifdef KMC_STAMPS
+    HIPCHK(c, hipMemcpyAsync(out, c->scratch_d, (size_t)c->R * 64, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+#else
+    (void)out;
+    return fail(c, KMC_ESTATE, "kmc_debug_stamps: this library was not built with -DKMC_STAMPS");
+#endif
 }
 
 int kmc_run(kmc_ctx* c, int64_t n_hops, int presim, const double* draws, uint64_t seed, int32_t* sel_out)

@@ -60,7 +60,16 @@ struct HopParams {
     long long* n_exact;          // [R]
     int* status;                 // [R]
     double* barrier;             // [R][5] last, sum, min, max, count
+    long long* stamps;           // [R][8] cycles per segment (-DKMC_STAMPS profiling builds only) or null
 };
+
+// Profiling builds (-DKMC_STAMPS, scripts/stamps.py) time the segments of a hop with s_memtime.
+#ifdef KMC_STAMPS
+#define KMC_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                          st_acc[k] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define KMC_STAMP(k) do {} while (0)
+#endif
 
 // The workgroup is ONE wave: its LDS instructions execute in issue order, so a
 // cross-lane LDS hand-off needs no s_barrier and no s_waitcnt, only a point the
@@ -176,6 +185,10 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
     const int ent_dir = lane - 6 * ent_site;
 
     const long long my_hops = p.n_hops_r ? p.n_hops_r[r] : p.n_hops;
+#ifdef KMC_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
     for (long long h0 = 0; h0 < my_hops && status == 0; h0 += KMC_WAVE) {
         const int cnt = (int)((my_hops - h0) < KMC_WAVE ? (my_hops - h0) : KMC_WAVE);
         // ---- uniforms for the next 64 hops, one hop per lane --------------
@@ -195,6 +208,7 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
         int idx_v = -1;
 
         int hl = 0;
+        KMC_STAMP(0);
         for (; hl < cnt; ++hl) {
             const double rho = readlane_f64(rho_v, hl);
             const double t = rho * gamma;
@@ -218,6 +232,7 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
                 if (ok) {
                     const int q = __ffsll((long long)mb) - 1;
                     const double blockbase = q > 0 ? readlane_f64(bp, q - 1) : rowbase;
+                    KMC_STAMP(1);
                     // ---- entry: 8 sites x 6 directions on 48 lanes -------------------------
                     const int js = q * 8 + ent_site;
                     double rate = 0.0;
@@ -257,6 +272,7 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
                 pnum = pick->c / g - pick->cprev / g;      // the reference's own expression (:497)
                 pden = 1.0;
             }
+            KMC_STAMP(2);
             const int s_src = i * ny + j;
             const int idx = s_src * 6 + d;
             // ---- update (:518-535) -------------------------------------------
@@ -294,6 +310,7 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
                 key[si * ny + sj] = knew;
             }
             wave_fence();
+            KMC_STAMP(3);
             // ---- tag move, deferred by one hop (:521-528) ------------------------------
             if (!p.presim) {
                 if (lane == 0) {
@@ -338,12 +355,14 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
                     if (act && grp_c == 2) blk[si * 8 + b2] = s2;
                 }
                 wave_fence();
+                KMC_STAMP(4);
                 int rel = lane - wrap1(i_lo, nx);
                 if (rel < 0) rel += nx;
                 if (rel < n_i && lane < nx) rsum = row_sum8(blk + lane * 8);
             }
             rowpre = wave_scan_incl(rsum);
             gamma = readlane_f64(rowpre, 63);
+            KMC_STAMP(5);
         }
         // ---- flush the chunk: clock, trace, barrier diagnostics ----------------------
         const int done = hl;                // hops of this chunk that executed
@@ -398,6 +417,11 @@ __global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
         p.barrier[r * 5 + 2] = fmin(p.barrier[r * 5 + 2], b_min);
         p.barrier[r * 5 + 3] = fmax(p.barrier[r * 5 + 3], b_max);
         p.barrier[r * 5 + 4] += b_cnt;
+#ifdef KMC_STAMPS
+        KMC_STAMP(6);
+        if (p.stamps)
+            for (int k = 0; k < 8; ++k) p.stamps[r * 8 + k] = (long long)st_acc[k];
+#endif
     }
 }
 

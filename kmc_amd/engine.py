@@ -231,6 +231,10 @@ class KMCEngine:
         self._chk(self._lib.kmc_gamma_exact(self._ctx, _ptr(g, C.c_double)))
         return g
 
+    def set_hop_kernel(self, generic=False):
+        """64 x 64 replicas: choose the any-size LDS kernel instead of the specialised one (tests)."""
+        self._chk(self._lib.kmc_set_hop_kernel(self._ctx, int(bool(generic))))
+
     def set_debug(self, force_exact=False, margin_scale=1.0):
         self._chk(self._lib.kmc_set_debug(self._ctx, int(bool(force_exact)), float(margin_scale)))
 

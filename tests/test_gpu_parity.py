@@ -249,6 +249,35 @@ def test_random_ensemble_vs_oracle(kmc, tables, dense, cfg):
         assert st['n_exact'].sum() <= 1
 
 
+# ---------------------------------------------------------------- 64 x 64 kernel vs any-size kernel
+@pytest.mark.parametrize('mode', ['hex_ref', 'obj_ref', 'full'])
+def test_lds64_kernel_equals_generic_kernel(kmc, tables, mode):
+    """The 64 x 64 specialisation keeps every sum's association, so traces, state, gamma and
+    clocks must be bit-identical to the any-size LDS kernel (which the oracle tests above
+    pin), here over 10^6 hops, all concentrations, certified and mixed exact-path modes."""
+    R, hp, hs, seed = 72, 4096 + 37, 10000, 0xC0FFEE
+    conc = np.repeat(np.linspace(0.1, 0.9, 9), 8)
+    out = []
+    for generic in (False, True):
+        with make_engine(kmc, tables, R, 64, 64, mode) as eng:
+            eng.set_hop_kernel(generic=generic)
+            eng.fill_random(conc, 99)
+            eng.rates_full()
+            i1 = eng.run(hp, presim=True, seed=seed, want_trace=True)
+            eng.init_displacements()
+            i2 = eng.run(hs, presim=False, seed=seed, want_trace=True)
+            eng.set_debug(force_exact=False, margin_scale=2e6)
+            i3 = eng.run(300, presim=False, seed=seed, want_trace=True)
+            sc, st = eng.scalars(), eng.status()
+            out.append((i1, i2, i3, eng.get_lattice(), eng.get_keys(), eng.get_displacements(), sc['time'],
+                        sc['step_time'], sc['gamma'], sc['hist'], st['n_exact'], st['status'],
+                        np.stack(list(eng.barrier_stats().values()))))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    assert out[0][10].sum() > 0 and not out[0][11].any()
+
+
+
 # ---------------------------------------------------------------- RNG streams / fill
 def test_fill_random_matches_philox(kmc, tables):
     R, nx, ny = 7, 30, 17
