@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (scripts/profile_bench.sh) into profiles/:
+   <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
+   <tag>_pmc.json           per-launch means of every counter for the dominant hop kernel
+   hbm_traffic.json         the HBM bytes per launch that bench.py reports as roofline.traffic
+usage: scripts/summarize_profile.py <tag> [kernel-substring]"""
+import csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+kern = sys.argv[2] if len(sys.argv) > 2 else 'hop_lds64_kernel'
+src = os.path.join(ROOT, 'gpurun_out', 'prof_' + tag)
+dst = os.path.join(ROOT, 'profiles')
+stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))[0]
+shutil.copy(stats, os.path.join(dst, tag + '_kernel_stats.csv'))
+out = {'tag': tag, 'kernel': kern, 'command': 'python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline', 'counters': {}}
+for row in csv.DictReader(open(stats)):
+    if kern in row['Name']:
+        out['kernel_trace'] = {'calls': int(row['Calls']), 'avg_ms': float(row['AverageNs']) / 1e6,
+                               'min_ms': float(row['MinNs']) / 1e6, 'max_ms': float(row['MaxNs']) / 1e6,
+                               'share_percent': float(row['Percentage'])}
+for f in sorted(glob.glob(os.path.join(src, 'pmc_*', '*', '*_counter_collection.csv'))):
+    acc = {}
+    for row in csv.DictReader(open(f)):
+        if kern in row['Kernel_Name']:
+            acc.setdefault(row['Counter_Name'], []).append(float(row['Counter_Value']))
+            out['dispatch'] = {k: row[k] for k in ('Grid_Size', 'Workgroup_Size', 'LDS_Block_Size', 'Scratch_Size',
+                                                  'VGPR_Count', 'Accum_VGPR_Count', 'SGPR_Count')}
+    for k, v in acc.items():
+        out['counters'][k] = {'mean_per_launch': sum(v) / len(v), 'launches': len(v)}
+c = out['counters']
+if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+    fetch_kb, write_kb = c['FETCH_SIZE']['mean_per_launch'], c['WRITE_SIZE']['mean_per_launch']
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE tallies 128-B
+    # requests at 64 B, so it is doubled; WRITE_SIZE is exact.  (Narrow gathers are uncalibrated: the
+    # doubled figure is the upper bound and the one reported.)
+    hbm = {'kernel': kern, 'tag': tag, 'replicas': 4096, 'hops_per_launch': 2048, 'fetch_size_kb': fetch_kb, 'write_size_kb': write_kb,
+           'fetch_correction': 2.0, 'hbm_bytes_per_launch': int((2.0 * fetch_kb + write_kb) * 1024),
+           'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py; '
+                     'profiles/%s_pmc.json' % tag}
+    json.dump(hbm, open(os.path.join(dst, 'hbm_traffic.json'), 'w'), indent=1)
+    out['hbm'] = hbm
+json.dump(out, open(os.path.join(dst, tag + '_pmc.json'), 'w'), indent=1)
+print(json.dumps(out, indent=1))
