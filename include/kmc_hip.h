@@ -152,6 +152,11 @@ int kmc_get_distances(kmc_ctx* ctx, double lattice_constant, double* matrix /* [
 int kmc_uses_lds_path(kmc_ctx* ctx);
 /* dynamic LDS bytes per replica of the hop kernel */
 int kmc_lds_bytes(kmc_ctx* ctx);
+/* 1 if the current rate table factors into the per-direction compact table Tc[6][2^13] (each folded rate
+ * reads 13 of the 18 key bits, hex_dict_builder.py:45-139) that the 64 x 64 kernel gathers from; a dense
+ * table given to kmc_set_hex_table that does not factor returns 0 and keeps the dense gather.
+ * No counterpart in the reference. */
+int kmc_table_is_compact(kmc_ctx* ctx);
 /* 64 x 64 replicas run a kernel specialised for that size (kmc_hop_lds64.h); generic != 0 selects the
  * any-size LDS kernel instead (tests compare the two).  No counterpart in the reference. */
 int kmc_set_hop_kernel(kmc_ctx* ctx, int generic);

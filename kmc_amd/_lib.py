@@ -55,6 +55,7 @@ SIGNATURES = {
     'kmc_get_distances': (C.c_int, [_ctx, C.c_double, _dp]),
     'kmc_uses_lds_path': (C.c_int, [_ctx]),
     'kmc_lds_bytes': (C.c_int, [_ctx]),
+    'kmc_table_is_compact': (C.c_int, [_ctx]),
     'kmc_set_hop_kernel': (C.c_int, [_ctx, C.c_int]),
     'kmc_debug_stamps': (C.c_int, [_ctx, _i64p]),
 }

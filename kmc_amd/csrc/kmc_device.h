@@ -74,10 +74,10 @@ __device__ __forceinline__ double group8_sum(double x)
     return x;
 }
 
-// Left-to-right sum of 8 consecutive doubles (a row's block sums).
+// Sum of 8 consecutive doubles (a row's block sums), the same tree as group8_sum.
 __device__ __forceinline__ double row_sum8(const double* b)
 {
-    return ((((((b[0] + b[1]) + b[2]) + b[3]) + b[4]) + b[5]) + b[6]) + b[7];
+    return ((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]));
 }
 
 __device__ __forceinline__ double readlane_f64(double x, int lane)
@@ -155,6 +155,50 @@ __device__ __forceinline__ double fold_rate(uint32_t row, int e, const double* b
         r2 = base512[ix];
     }
     return r1 + r2;                                        // :136-137
+}
+
+// ---------------------------------------------------------------- compact per-direction table
+// The folded rate of direction e depends on 13 of the key's 18 bits only: the end point, its two
+// side sites and the 2 x 9 sites of the two rotated views (hex_dict_builder.py:45-139).  So the
+// dense table T[2^18][6] (12.6 MB, larger than an XCD's 4 MB L2) factors into Tc[6][2^13]
+// (393 KB, L2 / L1 resident).  compact_mask(e) = the key bits (bit 17 - p for key char p)
+// direction e reads; the index is those bits packed together in ascending order.
+__host__ __device__ inline uint32_t compact_mask(int e)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int8_t* endp = kEndp;
+    const int8_t (*views)[2][9] = kViews;
+#else
+    static const int8_t endp[6] = {8, 4, 5, 9, 13, 12};
+    static const int8_t views[6][2][9] = {
+        {{5, 9, 4, 13, 3, 16, 7, 11, 15}, {13, 9, 12, 5, 11, 1, 7, 3, 0}},
+        {{9, 13, 5, 12, 1, 11, 0, 3, 7}, {12, 13, 8, 9, 3, 6, 0, 1, 2}},
+        {{13, 12, 9, 8, 6, 3, 2, 1, 0}, {8, 12, 4, 13, 1, 14, 2, 6, 10}},
+        {{12, 8, 13, 4, 14, 1, 10, 6, 2}, {4, 8, 5, 12, 6, 16, 10, 14, 17}},
+        {{8, 4, 12, 5, 16, 6, 17, 14, 10}, {5, 4, 9, 8, 14, 11, 17, 16, 15}},
+        {{4, 5, 8, 9, 11, 14, 15, 16, 17}, {9, 5, 13, 4, 16, 3, 15, 11, 7}}};
+#endif
+    uint32_t m = (1u << (17 - endp[e])) | (1u << (17 - endp[(e + 5) % 6])) | (1u << (17 - endp[(e + 1) % 6]));
+    for (int v = 0; v < 2; ++v)
+        for (int q = 0; q < 9; ++q) m |= 1u << (17 - views[e][v][q]);
+    return m;
+}
+#define KMC_COMPACT_BITS 13
+#define KMC_COMPACT_ROWS (1u << KMC_COMPACT_BITS)
+
+__host__ __device__ inline uint32_t pext18(uint32_t key, uint32_t mask)     // slow, table builders only
+{
+    uint32_t out = 0, o = 0;
+    for (int b = 0; b < 18; ++b)
+        if ((mask >> b) & 1u) { out |= ((key >> b) & 1u) << o; ++o; }
+    return out;
+}
+__host__ __device__ inline uint32_t pdep18(uint32_t idx, uint32_t mask)
+{
+    uint32_t out = 0, o = 0;
+    for (int b = 0; b < 18; ++b)
+        if ((mask >> b) & 1u) { out |= ((idx >> o) & 1u) << b; ++o; }
+    return out;
 }
 
 // Sum of the six rates of a table row in selection order; the hop kernels keep

@@ -40,6 +40,8 @@ struct kmc_ctx {
     int4* tags;
     double* table;
     double* wsum;
+    double* tcompact;      // [6][2^13] per-direction compact table, valid if have_compact
+    bool have_compact;
     double* time_total;
     double* step_time;
     double* gamma;
@@ -117,6 +119,28 @@ __global__ __launch_bounds__(256) void wsum_kernel(const double* __restrict__ ta
 #pragma unroll
     for (int e = 0; e < 6; ++e) r[e] = table[(size_t)row * 6 + e];
     wsum[row] = row_sum6(r);
+}
+
+// Compact table Tc[e][idx13] = T[pdep(idx13, mask_e)][e] and its verification against every entry
+// of the dense table (a user-supplied dense table need not factor; then the dense gather is kept).
+__global__ __launch_bounds__(256) void compact_build_kernel(const double* __restrict__ table, double* __restrict__ tc)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;          // 6 * 8192 threads
+    const int e = (int)(t >> KMC_COMPACT_BITS);
+    const uint32_t idx = t & (KMC_COMPACT_ROWS - 1);
+    tc[t] = table[(size_t)pdep18(idx, compact_mask(e)) * 6 + e];
+}
+
+__global__ __launch_bounds__(256) void compact_verify_kernel(const double* __restrict__ table, const double* __restrict__ tc,
+                                                             int* __restrict__ mismatches)
+{
+    const uint32_t key = blockIdx.x * 256 + threadIdx.x;
+    int bad = 0;
+    for (int e = 0; e < 6; ++e) {
+        const double a = table[(size_t)key * 6 + e], b = tc[((size_t)e << KMC_COMPACT_BITS) + pext18(key, compact_mask(e))];
+        bad += __double_as_longlong(a) != __double_as_longlong(b);
+    }
+    if (bad) atomicAdd(mismatches, bad);
 }
 
 // Row G.  hex_LiCoO2_kmc.py:103-199 + :402-403, one thread per base key.
@@ -428,11 +452,13 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     CREATE_CHK(hipMalloc((void**)&c->occ, Rn + 16));
     CREATE_CHK(hipMalloc((void**)&c->keys, Rn * 4 + 16));
     CREATE_CHK(hipMalloc((void**)&c->tags, Rn * 16 + 16));
-    // one extra all-zero row (index 2^18): the key of a vacant site inside hop_lds64_kernel
-    CREATE_CHK(hipMalloc((void**)&c->table, (size_t)(KMC_TABLE_ROWS + 1) * 6 * 8));
-    CREATE_CHK(hipMalloc((void**)&c->wsum, (size_t)(KMC_TABLE_ROWS + 1) * 8));
-    CREATE_CHK(hipMemsetAsync(c->table + (size_t)KMC_TABLE_ROWS * 6, 0, 48, c->stream));
-    CREATE_CHK(hipMemsetAsync(c->wsum + KMC_TABLE_ROWS, 0, 8, c->stream));
+    // 2^19 rows: hop_lds64_kernel keys a vacant site as 0x7FFFF (bit 18 + all neighbours Li), whose
+    // row is all zeros; rows 2^18 .. 2^19-2 are never touched
+    CREATE_CHK(hipMalloc((void**)&c->table, (size_t)(2 * KMC_TABLE_ROWS) * 6 * 8));
+    CREATE_CHK(hipMalloc((void**)&c->wsum, (size_t)(2 * KMC_TABLE_ROWS) * 8));
+    CREATE_CHK(hipMemsetAsync(c->table + (size_t)(2 * KMC_TABLE_ROWS - 1) * 6, 0, 48, c->stream));
+    CREATE_CHK(hipMemsetAsync(c->wsum + (2 * KMC_TABLE_ROWS - 1), 0, 8, c->stream));
+    CREATE_CHK(hipMalloc((void**)&c->tcompact, (size_t)6 * KMC_COMPACT_ROWS * 8));
     CREATE_CHK(hipMalloc((void**)&c->time_total, c->R * 8));
     CREATE_CHK(hipMalloc((void**)&c->step_time, c->R * 8));
     CREATE_CHK(hipMalloc((void**)&c->gamma, c->R * 8));
@@ -454,7 +480,8 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     CREATE_CHK(hipMemsetAsync(c->status, 0, c->R * 4, c->stream));
     c->lds64 = c->lds_path && nx == 64 && ny == 64;
     if (c->lds_path) {
-        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, K64_LDS_BYTES));
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, K64_LDS_BYTES));
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, K64_LDS_BYTES));
         const size_t lds = host_hop_lds_bytes(c->nx, c->n);
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (nx <= 4096) {
@@ -475,7 +502,7 @@ int kmc_destroy(kmc_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* bufs[] = {c->occ, c->keys, c->tags, c->table, c->wsum, c->time_total, c->step_time, c->gamma, c->hist,
-                    c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel, c->w_g};
+                    c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel, c->w_g, c->tcompact};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -532,6 +559,22 @@ int kmc_set_hop_kernel(kmc_ctx* c, int generic)
 }
 
 // ---------------------------------------------------------------- tables
+static int build_compact(kmc_ctx* c)
+{
+    int* flag = reinterpret_cast<int*>(c->scratch_d);
+    HIPCHK(c, hipMemsetAsync(flag, 0, 4, c->stream));
+    compact_build_kernel<<<6 * KMC_COMPACT_ROWS / 256, 256, 0, c->stream>>>(c->table, c->tcompact);
+    compact_verify_kernel<<<KMC_TABLE_ROWS / 256, 256, 0, c->stream>>>(c->table, c->tcompact, flag);
+    HIPCHK(c, hipGetLastError());
+    int bad = 0;
+    HIPCHK(c, hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_compact = bad == 0;
+    return KMC_OK;
+}
+
+int kmc_table_is_compact(kmc_ctx* c) { return c && c->have_compact ? 1 : 0; }
+
 int kmc_set_base_table(kmc_ctx* c, const double* base512, double dumbbell)
 {
     CTXCHK(c);
@@ -546,7 +589,7 @@ int kmc_set_base_table(kmc_ctx* c, const double* base512, double dumbbell)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipFree(dbase));
     c->have_table = true;
-    return KMC_OK;
+    return build_compact(c);
 }
 
 int kmc_set_hex_table(kmc_ctx* c, const double* table)
@@ -558,7 +601,7 @@ int kmc_set_hex_table(kmc_ctx* c, const double* table)
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_table = true;
-    return KMC_OK;
+    return build_compact(c);
 }
 
 int kmc_get_hex_table(kmc_ctx* c, double* table)
@@ -865,8 +908,11 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     const int slot = (int)(c->run_launches % KMC_EV_RING);
     time_begin(c);
     HIPCHK(c, hipEventRecord(c->run_ev[slot][0], c->stream));
-    if (c->lds64)
-        hop_lds64_kernel<<<c->R, 64, K64_LDS_BYTES, c->stream>>>(p);
+    p.tcompact = c->tcompact;
+    if (c->lds64 && c->have_compact)
+        hop_lds64_kernel<true><<<c->R, 64, K64_LDS_BYTES, c->stream>>>(p);
+    else if (c->lds64)
+        hop_lds64_kernel<false><<<c->R, 64, K64_LDS_BYTES, c->stream>>>(p);
     else
         hop_lds_kernel<<<c->R, 64, host_hop_lds_bytes(c->nx, c->n), c->stream>>>(p);
     HIPCHK(c, hipEventRecord(c->run_ev[slot][1], c->stream));

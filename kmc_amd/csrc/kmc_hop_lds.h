@@ -46,6 +46,7 @@ struct HopParams {
     double mfac;                 // (6n + 256) * 2^-53 * 1.001 * margin_scale
     const double* table;         // [2^18][6]
     const double* wsum;          // [2^18]
+    const double* tcompact;      // [6][2^13] per-direction compact table (hop_lds64_kernel<true>) or null
     uint8_t* occ;                // [R][n]
     uint32_t* keys;              // [R][n]
     int4* tags;                  // [R][n]  i0, j0, wi, wj

@@ -231,6 +231,10 @@ class KMCEngine:
         self._chk(self._lib.kmc_gamma_exact(self._ctx, _ptr(g, C.c_double)))
         return g
 
+    def table_is_compact(self):
+        """True if the rate table factors into the compact per-direction table (include/kmc_hip.h)."""
+        return bool(self._lib.kmc_table_is_compact(self._ctx))
+
     def set_hop_kernel(self, generic=False):
         """64 x 64 replicas: choose the any-size LDS kernel instead of the specialised one (tests)."""
         self._chk(self._lib.kmc_set_hop_kernel(self._ctx, int(bool(generic))))

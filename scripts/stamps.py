@@ -27,7 +27,7 @@ eng.fill_random(0.5, 1); eng.rates_full(); eng.sync()
 eng.run(H, presim=True, seed=3); eng.sync()
 eng.init_displacements()
 names = ['chunk setup (draws, flush)', 'row + block pick', 'entry gather + scan + certify', 'update + window keys',
-         'tag + block re-sum (W gathers)', 'row re-sum + row scan', 'epilogue', '-']
+         'block re-sum (W gathers) + row sums', 'bpermute + row scan', 'tag ops (part of update)', 'early reads + bitmaps (part of update)']
 for presim in (True, False):
     eng.run(H, presim=presim, seed=3); eng.sync()
     st = np.zeros((R, 8), dtype=np.int64)
@@ -35,6 +35,6 @@ for presim in (True, False):
     assert rc == 0, rc
     print('presim' if presim else 'sim', 'kernel %.3f ms' % eng.last_kernel_ms())
     tot = st.sum(axis=1).mean()
-    for k in range(7):
+    for k in range(8):
         print('  %-34s %9.1f cycles/hop  %5.1f %%' % (names[k], st[:, k].mean() / H, 100 * st[:, k].mean() / tot))
     print('  %-34s %9.1f cycles/hop (memtime ticks; 100 MHz-based if constant clock)' % ('total', tot / H))

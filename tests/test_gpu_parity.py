@@ -278,6 +278,35 @@ def test_lds64_kernel_equals_generic_kernel(kmc, tables, mode):
 
 
 
+def test_dense_table_that_does_not_factor(kmc, tables, dense):
+    """A user table (kmc_set_hex_table) need not depend on 13 key bits per direction only: the
+    engine must notice and keep the dense gather; trajectories still match the oracle."""
+    rs = np.random.RandomState(5)
+    dense2 = dense * (1.0 + 0.25 * rs.rand(*dense.shape))        # same zeros, key-dependent values
+    R, hp, hs = 3, 700, 1300
+    occ = np.stack([(rs.rand(64, 64) < c).astype(np.int8) for c in (0.3, 0.5, 0.7)])
+    d_pre = np.stack([rs.rand(R, hp), np.ones((R, hp))], axis=-1)
+    d_sim = rs.rand(R, hs, 2)
+    with kmc.KMCEngine(R, 64, 64) as eng:
+        eng.set_base_table(tables[0]['base512_normcons'], kmc.tables.dumbbell_rate())
+        assert eng.table_is_compact()
+        eng.set_hex_table(dense2)
+        assert not eng.table_is_compact()
+        eng.set_lattice(occ)
+        eng.rates_full()
+        i1 = eng.run(hp, presim=True, draws=d_pre, want_trace=True)
+        eng.init_displacements()
+        i2 = eng.run(hs, presim=False, draws=d_sim, want_trace=True)
+        got, lat, tags, sc = np.concatenate([i1, i2], axis=1), eng.get_lattice(), eng.get_reference_tags(), eng.scalars()
+        eng.set_hex_table(dense)
+        assert eng.table_is_compact()
+    for r in range(R):
+        rep, idx = _oracle_run(occ[r], dense2, 'hex_ref', d_pre[r], d_sim[r], None)
+        assert np.array_equal(got[r], idx)
+        assert np.array_equal(lat[r], rep.occ) and np.array_equal(tags[r], rep.tags)
+        np.testing.assert_allclose(sc['time'][r], rep.time.value, rtol=RTOL)
+
+
 # ---------------------------------------------------------------- RNG streams / fill
 def test_fill_random_matches_philox(kmc, tables):
     R, nx, ny = 7, 30, 17
