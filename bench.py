@@ -114,6 +114,7 @@ def main():
     eng.init_displacements()
     for _ in range(args.warmup):
         eng.run(hops_per_step, presim=False, seed=seed + rank)
+    eng.diffusion(CONC)              # warm-up of the exchange step too (first call loads its kernel)
     eng.sync()
 
     def barrier():

@@ -295,22 +295,6 @@ void hop_lds64_kernel(HopParams p)
             const int ie = ii + di, je = j + dj;                 // unwrapped
             const int iw = ie & 63, jw = je & 63;
             const int s_dst = iw * 64 + jw;
-            // ---- tag move (:521-528): book-keeping only, memory is touched at the chunk flush
-            if (!presim) {
-                const unsigned long long m = ballot64(tg_site == s_src) & tg_live;
-                // tg_ow = origin lane | (wi + 64) << 8 | (wj + 64) << 16; |w| <= 64 inside a chunk
-                int ow = hl | (64 << 8) | (64 << 16);
-                if (m) {
-                    // the atom came with an earlier hop of this chunk: inherit its origin and wraps
-                    ow = __builtin_amdgcn_readlane(tg_ow, __ffsll((long long)m) - 1);
-                    tg_live &= ~m;
-                } else {
-                    tg_root |= 1ull << hl;                       // its tag is still in memory, at s_src
-                }
-                ow += ((ie >> 6) << 8) + ((je >> 6) << 16);      // wrap: floor(ie / 64) = -1, 0, +1
-                if (lane == hl) { tg_site = s_dst; tg_ow = ow; tg_vac = s_src; }
-                tg_live |= 1ull << hl;
-            }
             KMC_STAMP(6);
             // ---- window geometry (:444-453): group a = window row a, its 8 lanes = the 8 sites
             // (c, c + 8 apart) of the two blocks b0, b1 the window's columns fall in
@@ -328,9 +312,6 @@ void hop_lds64_kernel(HopParams p)
             if (lane == j) cb &= ~(1ull << ii);
             if (lane == jw) cb |= (1ull << iw);
             if (lane == j || lane == jw) write_col();
-            hist_c += (lane == d);
-            if (lane == hl) { gam_v = gamma; pn_v = pnum; idx_v = idx | exact_flag; }
-            ++hops;
             wave_fence();
             KMC_STAMP(7);
             // ---- windowed refresh (:453-465): this lane's window column is the one = c (mod 8)
@@ -376,6 +357,26 @@ void hop_lds64_kernel(HopParams p)
             // ---- re-sum the touched blocks (8 lanes per block) and rows -------------------
             double w0 = 0.0, w1 = 0.0;
             if (act) { w0 = load_w(k0); w1 = load_w(k1); }
+            // ---- book-keeping that nothing in this hop waits for runs while the gathers are in flight
+            hist_c += (lane == d);
+            if (lane == hl) { gam_v = gamma; pn_v = pnum; idx_v = idx | exact_flag; }
+            ++hops;
+            // tag move (:521-528): registers only, memory is touched at the chunk flush
+            if (!presim) {
+                const unsigned long long m = ballot64(tg_site == s_src) & tg_live;
+                // tg_ow = origin lane | (wi + 64) << 8 | (wj + 64) << 16; |w| <= 64 inside a chunk
+                int ow = hl | (64 << 8) | (64 << 16);
+                if (m) {
+                    // the atom came with an earlier hop of this chunk: inherit its origin and wraps
+                    ow = __builtin_amdgcn_readlane(tg_ow, __ffsll((long long)m) - 1);
+                    tg_live &= ~m;
+                } else {
+                    tg_root |= 1ull << hl;                       // its tag is still in memory, at s_src
+                }
+                ow += ((ie >> 6) << 8) + ((je >> 6) << 16);      // wrap: floor(ie / 64) = -1, 0, +1
+                if (lane == hl) { tg_site = s_dst; tg_ow = ow; tg_vac = s_src; }
+                tg_live |= 1ull << hl;
+            }
             const double s0 = group8_sum(w0);
             const double s1 = group8_sum(w1);
             if (act && grp_c == 0) blk[si * 8 + b0] = s0;
