@@ -26,8 +26,9 @@ eng.set_base_table(t['base512_normcons'], kmc_amd.tables.dumbbell_rate())
 eng.fill_random(0.5, 1); eng.rates_full(); eng.sync()
 eng.run(H, presim=True, seed=3); eng.sync()
 eng.init_displacements()
-names = ['chunk setup (draws, flush)', 'row + block pick', 'entry gather + scan + certify', 'update + window keys',
-         'block re-sum (W gathers) + row sums', 'bpermute + row scan', 'tag ops (part of update)', 'early reads + bitmaps (part of update)']
+names = ['chunk setup + flush (draws, clock, tags)', 'row + block pick', 'entry: key, Tc gather, scan, certify',
+         'window keys (column reads, key assembly)', 'W gathers + book-keeping + block / row sums', 'bpermute + row scan',
+         'update scalars (after pick)', 'early reads + bitmaps']
 for presim in (True, False):
     eng.run(H, presim=presim, seed=3); eng.sync()
     st = np.zeros((R, 8), dtype=np.int64)
