@@ -862,7 +862,10 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         HIPCHK(c, hipMemcpyAsync(dcounts, counts, (size_t)c->R * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    const double mfac = (6.0 * c->n + 256.0) * ldexp(1.0, -53) * 1.001 * c->margin_scale;
+    // 6n: the reference's sequential cumsum; 6n / 8192: np.sum adds its buffers left to right; 512: the
+    // roundings of the kernels' own hierarchical sums (<= 70), np.sum inside a buffer (<= 30), fl(rho * gamma),
+    // the 2u of fl(c / gamma) >= rho
+    const double mfac = (6.0 * c->n * (1.0 + 1.0 / 8192.0) + 512.0) * ldexp(1.0, -53) * 1.001 * c->margin_scale;
     if (!c->lds_path) {
         if (!c->w_g) HIPCHK(c, hipMalloc((void**)&c->w_g, (size_t)c->R * c->n * 8));
         HopGlobalParams g;

@@ -9,12 +9,13 @@
 //   sites -> the same over w[row][0..ny)
 //   dir   -> six table rates
 // followed by the window refresh (keys from byte occupancy), the re-sum of the
-// touched rows and, when the certification margin is not met, an exact
-// block-parallel replay of the reference's np.sum / sequential cumsum.
+// touched rows and, when the certification margin is not met, the exact
+// block-parallel replay of the reference's np.sum / sequential cumsum (kmc_exact_par.h).
 // Per hop it reads O(nx + 6*ny) values instead of the reference's 6*nx*ny.
 #pragma once
 #include "kmc_device.h"
 #include "kmc_hop_lds.h"
+#include "kmc_exact_par.h"
 
 namespace kmc {
 
@@ -45,13 +46,7 @@ struct GbShared {
     int first_thread;
     int i, j, d, ok;
     double rowbase, sitebase, lo, hi, pnorm;
-    // exact path
-    double chunk_sum[KMC_GB_WAVES];
-    double ex_gamma, ex_c, ex_cprev;
-    long long ex_idx;
-    int ex_found;
-    PwFrame frames[KMC_PW_DEPTH];
-    double stage[KMC_GB_THREADS * 6];
+    ExactParShared xp;           // exact path (kmc_exact_par.h)
 };
 
 // inclusive block scan (fixed association): wave scan, then the totals of the
@@ -85,89 +80,6 @@ __device__ __forceinline__ int block_first(bool flag, GbShared* sh)
     const int f = sh->first_thread;
     __syncthreads();
     return f;
-}
-
-// Exact replay of hex_LiCoO2_kmc.py:486-492 by the whole workgroup.
-__device__ __noinline__ void exact_select_block(const uint32_t* __restrict__ keys, const double* __restrict__ table,
-                                                int n, double rho, GbShared* sh)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    auto entry = [&](long e) -> double {
-        const int s = (int)(e / 6);
-        const int d = (int)(e - 6 * (long)s);
-        const uint32_t k = keys[s];
-        return k == KMC_VACANT ? 0.0 : table[(size_t)k * 6 + d];
-    };
-    // ---- np.sum: full 8192-element buffers, one wave each (lane = 128-element leaf)
-    const long n6 = 6L * n;
-    const long nfull = n6 / 8192;
-    double total = 0.0;                                   // meaningful in thread 0
-    for (long c0 = 0; c0 < nfull; c0 += KMC_GB_WAVES) {
-        const long c = c0 + wv;
-        if (c < nfull) {
-            const long lo = c * 8192 + (long)lane * 128;
-            double r0 = entry(lo), r1 = entry(lo + 1), r2 = entry(lo + 2), r3 = entry(lo + 3),
-                   r4 = entry(lo + 4), r5 = entry(lo + 5), r6 = entry(lo + 6), r7 = entry(lo + 7);
-            for (long i = 8; i < 128; i += 8) {
-                r0 += entry(lo + i); r1 += entry(lo + i + 1); r2 += entry(lo + i + 2); r3 += entry(lo + i + 3);
-                r4 += entry(lo + i + 4); r5 += entry(lo + i + 5); r6 += entry(lo + i + 6); r7 += entry(lo + i + 7);
-            }
-            double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-            // pairwise tree over the 64 leaves: lower half + upper half at every level
-            for (int b = 1; b < 64; b <<= 1) {
-                const double other = __shfl_xor(res, b, 64);
-                res = (lane & b) ? other + res : res + other;
-            }
-            if (lane == 0) sh->chunk_sum[wv] = res;
-        }
-        __syncthreads();
-        if (tid == 0)
-            for (int q = 0; q < KMC_GB_WAVES && c0 + q < nfull; ++q) total = total + sh->chunk_sum[q];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const long tail = n6 - nfull * 8192;
-        if (tail > 0) total = total + np_pairwise(nfull * 8192, tail, entry, sh->frames);
-        sh->ex_gamma = total;
-        sh->ex_found = 0;
-        sh->ex_idx = n6;
-        sh->ex_c = 0.0;
-        sh->ex_cprev = 0.0;
-        if (0.0 / total >= rho) { sh->ex_found = 1; sh->ex_idx = 0; }     // searchsorted(left), rho <= 0
-    }
-    __syncthreads();
-    const double gamma = sh->ex_gamma;
-    // anything below thr cannot satisfy fl(c / gamma) >= rho: one compare instead of a division per entry
-    const double thr = rho * gamma * (1.0 - 0x1p-50);
-    // ---- sequential cumsum, staged 256 sites at a time
-    for (int s0 = 0; s0 < n && !sh->ex_found; s0 += KMC_GB_THREADS) {
-        const int s = s0 + tid;
-        double r[6] = {0, 0, 0, 0, 0, 0};
-        if (s < n) {
-            const uint32_t k = keys[s];
-            if (k != KMC_VACANT) {
-                const double2* t = reinterpret_cast<const double2*>(table + (size_t)k * 6);
-                const double2 a = t[0], b = t[1], c = t[2];
-                r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y; r[4] = c.x; r[5] = c.y;
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < 6; ++d) sh->stage[tid * 6 + d] = r[d];
-        __syncthreads();
-        if (tid == 0) {
-            double c = sh->ex_c, cprev = sh->ex_cprev;
-            const int m = (n - s0) < KMC_GB_THREADS ? (n - s0) : KMC_GB_THREADS;
-            for (int e = 0; e < m * 6; ++e) {
-                const double pv = sh->stage[e];
-                if (pv == 0.0) continue;               // + 0.0 changes nothing
-                cprev = c;
-                c += pv;
-                if (c >= thr && c / gamma >= rho) { sh->ex_found = 1; sh->ex_idx = (long long)s0 * 6 + e; break; }
-            }
-            sh->ex_c = c; sh->ex_cprev = cprev;
-        }
-        __syncthreads();
-    }
 }
 
 __global__ __launch_bounds__(KMC_GB_THREADS) void hop_global_kernel(HopGlobalParams p)
@@ -304,16 +216,16 @@ __global__ __launch_bounds__(KMC_GB_THREADS) void hop_global_kernel(HopGlobalPar
         double pnorm;
         if (!ok) {
             __syncthreads();
-            exact_select_block(keys, p.table, n, rho, sh);
+            exact_select_par(keys, p.table, n, rho, &sh->xp);
             ++n_exact;
-            const long long idx = sh->ex_idx;
-            const double g = sh->ex_gamma;
+            const long long idx = sh->xp.idx;
+            const double g = sh->xp.gamma;
             if (!(g > 0.0)) { status = 2; break; }
             if (idx >= 6LL * n) { status = 1; break; }
             d = (int)(idx % 6);
             j = (int)((idx / 6) % ny);
             i = (int)((idx / 6) / ny);
-            pnorm = sh->ex_c / g - sh->ex_cprev / g;
+            pnorm = sh->xp.c_found / g - sh->xp.cprev_found / g;
         } else {
             j = sh->j; d = sh->d; pnorm = sh->pnorm;
         }
