@@ -35,6 +35,7 @@ struct ExactParShared {
     double chunk_sum[KMC_XP_WAVES];
     long long wave_tot[KMC_XP_WAVES];
     unsigned long long ev;                   // earliest event of the pass: entry index << 1 | type
+    int any;                                 // some thread of the pass has to look closer
     double c;                                // exact cumsum in front of entry `pos`
     long long pos;
     double gamma, cstar, c_found, cprev_found;
@@ -43,13 +44,58 @@ struct ExactParShared {
     PwFrame frames[KMC_PW_DEPTH];
 };
 
+#ifdef KMC_XP_TRACE
+__device__ volatile long long* g_xp_trace = nullptr;      // scripts/probes/xp_probe.hip: progress in pinned host memory
+#define XP_TRACE(slot, val) do { if (threadIdx.x == 0 && g_xp_trace) g_xp_trace[slot] = (long long)(val); } while (0)
+#else
+#define XP_TRACE(slot, val) do {} while (0)
+#endif
+
 __device__ __forceinline__ double ulp_step(double x, int dir)    // x > 0
 {
     return __longlong_as_double(__double_as_longlong(x) + dir);
 }
 
+__device__ __forceinline__ uint32_t xp_row(uint32_t k) { return k > 0x3FFFFu ? 0x7FFFFu : k; }   // vacant -> zero row
+
+// numpy's 128-element leaf (8 interleaved accumulators) over entries [lo, lo + 128) of the flattened
+// rate matrix, lo % 6 == O.  Everything is unrolled with compile-time positions so that the 22 rows
+// the leaf covers are loaded as independent 16-byte loads and stay in registers.
+template <int O>
+__device__ __forceinline__ double xp_leaf128(const uint32_t* __restrict__ keys, const double* __restrict__ table, long lo)
+{
+    const long s0 = (lo - O) / 6;
+    double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool first[8] = {true, true, true, true, true, true, true, true};
+#pragma unroll
+    for (int b = 0; b < 22; b += 4) {                     // batches of 4 sites
+        double v[4][6];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (b + q < 22) {
+                const double2* t = reinterpret_cast<const double2*>(table + (size_t)xp_row(keys[s0 + b + q]) * 6);
+                const double2 x = t[0], y = t[1], z = t[2];
+                v[q][0] = x.x; v[q][1] = x.y; v[q][2] = y.x; v[q][3] = y.y; v[q][4] = z.x; v[q][5] = z.y;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int d = 0; d < 6; ++d) {
+                const int e = (b + q) * 6 + d - O;        // position inside the leaf
+                if (b + q < 22 && e >= 0 && e < 128) {
+                    if (first[e & 7]) { r[e & 7] = v[q][d]; first[e & 7] = false; }
+                    else r[e & 7] += v[q][d];
+                }
+            }
+        }
+    }
+    return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+}
+
 // Result in sh->idx, sh->gamma, sh->c_found, sh->cprev_found (every thread may read them after the
-// call; the call ends with a barrier).  keys: KMC_VACANT = vacant.
+// call; the call ends with a barrier).  keys: KMC_VACANT = vacant; table must have the all-zero row
+// 0x7FFFF (kmc_create allocates 2^19 rows for that).
 __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys, const double* __restrict__ table,
                                               int n, double rho, ExactParShared* sh)
 {
@@ -57,8 +103,7 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
     auto entry = [&](long e) -> double {
         const int s = (int)(e / 6);
         const int d = (int)(e - 6 * (long)s);
-        const uint32_t k = keys[s];
-        return k == KMC_VACANT ? 0.0 : table[(size_t)k * 6 + d];
+        return table[(size_t)xp_row(keys[s]) * 6 + d];
     };
     // ---- np.sum: full 8192-element buffers, one wave each (lane = 128-element leaf)
     const long n6 = 6L * n;
@@ -68,13 +113,8 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
         const long c = c0 + wv;
         if (c < nfull) {
             const long lo = c * 8192 + (long)lane * 128;
-            double r0 = entry(lo), r1 = entry(lo + 1), r2 = entry(lo + 2), r3 = entry(lo + 3),
-                   r4 = entry(lo + 4), r5 = entry(lo + 5), r6 = entry(lo + 6), r7 = entry(lo + 7);
-            for (long i = 8; i < 128; i += 8) {
-                r0 += entry(lo + i); r1 += entry(lo + i + 1); r2 += entry(lo + i + 2); r3 += entry(lo + i + 3);
-                r4 += entry(lo + i + 4); r5 += entry(lo + i + 5); r6 += entry(lo + i + 6); r7 += entry(lo + i + 7);
-            }
-            double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+            const int o = (int)(lo % 6);                  // 0, 2 or 4: 8192 and 128 are both 2 (mod 6)
+            double res = o == 0 ? xp_leaf128<0>(keys, table, lo) : (o == 2 ? xp_leaf128<2>(keys, table, lo) : xp_leaf128<4>(keys, table, lo));
             // pairwise tree over the 64 leaves: lower half + upper half at every level
             for (int b = 1; b < 64; b <<= 1) {
                 const double other = __shfl_xor(res, b, 64);
@@ -110,55 +150,73 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
         }
     }
     __syncthreads();
+    XP_TRACE(0, 1);
     if (sh->done) return;
     const double cstar = sh->cstar;
     const long long two53 = 1LL << 53, two54 = 1LL << 54;
+    const double magic = 4503599627370496.0;              // 2^52
 
+    uint32_t knext[KMC_XP_SITES];
+#pragma unroll
+    for (int q = 0; q < KMC_XP_SITES; ++q) {
+        const long s = (long)tid * KMC_XP_SITES + q;
+        knext[q] = s < n ? keys[s] : KMC_VACANT;
+    }
     for (long tile0 = 0; tile0 < n6; tile0 += KMC_XP_TILE) {
         const long tile_end = (tile0 + KMC_XP_TILE) < n6 ? (tile0 + KMC_XP_TILE) : n6;
         const long e0 = tile0 + (long)tid * (KMC_XP_SITES * 6);
         double p[KMC_XP_SITES * 6];
 #pragma unroll
         for (int q = 0; q < KMC_XP_SITES; ++q) {
-            const long s = e0 / 6 + q;
-            double2 a = make_double2(0, 0), b = a, c = a;
-            if (s < n) {
-                const uint32_t k = keys[s];
-                if (k != KMC_VACANT) {
-                    const double2* t = reinterpret_cast<const double2*>(table + (size_t)k * 6);
-                    a = t[0]; b = t[1]; c = t[2];
-                }
-            }
+            const double2* t = reinterpret_cast<const double2*>(table + (size_t)xp_row(knext[q]) * 6);
+            const double2 a = t[0], b = t[1], c = t[2];
             p[q * 6 + 0] = a.x; p[q * 6 + 1] = a.y; p[q * 6 + 2] = b.x; p[q * 6 + 3] = b.y; p[q * 6 + 4] = c.x; p[q * 6 + 5] = c.y;
         }
+#pragma unroll
+        for (int q = 0; q < KMC_XP_SITES; ++q) {          // the next tile's keys travel while this one is summed
+            const long s = (e0 + KMC_XP_TILE) / 6 + q;
+            knext[q] = s < n ? keys[s] : KMC_VACANT;
+        }
         for (;;) {                                        // segments of the tile between events
-            if (tid == 0) sh->ev = KMC_XP_NOEV;
+            if (tid == 0) { sh->ev = KMC_XP_NOEV; sh->any = 0; }
             __syncthreads();
             const double c = sh->c;
             const long pos = sh->pos;
+            XP_TRACE(1, tile0); XP_TRACE(2, pos); XP_TRACE(3, __double_as_longlong(c)); XP_TRACE(4, g_xp_trace[4] + 1);
             if (sh->done || pos >= tile_end) break;
             int ex = 0;
             long long A = 0;
-            if (c > 0.0) { ex = ilogb(c); A = (long long)ldexp(c, 52 - ex); }
-            auto quantum = [&](double pv, bool* tie) -> long long {      // RN(pv / U), saturated at 2^53
-                const double y = ldexp(pv, 52 - ex);
-                *tie = false;
-                if (y >= 9007199254740992.0) return two53;
-                const double fl = floor(y);
-                *tie = (y - fl) == 0.5;
-                return (long long)rint(y);
+            double scale = 0.0;
+            if (c > 0.0) { ex = ilogb(c); A = (long long)ldexp(c, 52 - ex); scale = ldexp(1.0, 52 - ex); }
+            // RN(pv / U) for pv / U < 2^52 - 1 through the 2^52 trick; anything larger, and exact ties,
+            // are left to the reference's own addition (an event)
+            auto quantum = [&](double pv, bool* special) -> long long {
+                const double y = pv * scale;              // exact: scale is a power of two
+                const double z = y + magic;
+                const double qd = z - magic;
+                *special = !(y < magic - 1.0) || fabs(qd - y) == 0.5;
+                return __double_as_longlong(z) & ((1LL << 52) - 1);
             };
-            // pass 1: this thread's integer total, block-exclusive scan
+            // pass 1: this thread's integer total and whether it needs a closer look
             long long run = 0;
+            bool flag = false;
             if (c > 0.0) {
 #pragma unroll
                 for (int m = 0; m < KMC_XP_SITES * 6; ++m) {
                     const long em = e0 + m;
                     if (em >= pos && em < tile_end) {
-                        bool tie;
-                        run += quantum(p[m], &tie);
-                        run = run < two54 ? run : two54;
+                        bool sp;
+                        const long long q = quantum(p[m], &sp);
+                        flag = flag || sp;
+                        run += q;
                     }
+                }
+                if (flag) run = two54;                    // saturate: everything behind an event is void
+            } else {
+#pragma unroll
+                for (int m = 0; m < KMC_XP_SITES * 6; ++m) {
+                    const long em = e0 + m;
+                    flag = flag || (em >= pos && em < tile_end && p[m] > 0.0);
                 }
             }
             long long incl = run;
@@ -174,31 +232,40 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
                 if (q < wv) base += sh->wave_tot[q];
                 tot += sh->wave_tot[q];
             }
-            // pass 2: this thread's first event
+            if (c > 0.0) {
+                const long long endv = base + run;
+                flag = flag || endv >= two53 || ldexp((double)endv, ex - 52) >= cstar;
+            }
+            if (flag) sh->any = 1;
+            __syncthreads();
+            const bool any = sh->any != 0;                // false on the common tile: no event, the sum just moves on
+            // pass 2: flagged threads look for their first event
             unsigned long long myev = KMC_XP_NOEV;
             double ev_before = 0.0, ev_after = 0.0, ev_p = 0.0;
+            if (any && flag) {
 #pragma unroll
-            for (int m = 0; m < KMC_XP_SITES * 6; ++m) {
-                const long em = e0 + m;
-                if (myev == KMC_XP_NOEV && em >= pos && em < tile_end) {
-                    if (c > 0.0) {
-                        bool tie;
-                        const long long q = quantum(p[m], &tie);
-                        const long long after = base + q;
-                        if (tie || after >= two53) {          // the reference's own add decides
-                            myev = ((unsigned long long)em << 1) | 0ull;
-                            ev_before = ldexp((double)base, ex - 52); ev_p = p[m];
-                        } else {
-                            const double ca = ldexp((double)after, ex - 52);
-                            if (ca >= cstar) {
-                                myev = ((unsigned long long)em << 1) | 1ull;
-                                ev_before = ldexp((double)base, ex - 52); ev_after = ca;
+                for (int m = 0; m < KMC_XP_SITES * 6; ++m) {
+                    const long em = e0 + m;
+                    if (myev == KMC_XP_NOEV && em >= pos && em < tile_end) {
+                        if (c > 0.0) {
+                            bool sp;
+                            const long long q = quantum(p[m], &sp);
+                            const long long after = base + q;
+                            if (sp || after >= two53) {           // the reference's own add decides
+                                myev = ((unsigned long long)em << 1) | 0ull;
+                                ev_before = ldexp((double)base, ex - 52); ev_p = p[m];
+                            } else {
+                                const double ca = ldexp((double)after, ex - 52);
+                                if (ca >= cstar) {
+                                    myev = ((unsigned long long)em << 1) | 1ull;
+                                    ev_before = ldexp((double)base, ex - 52); ev_after = ca;
+                                }
                             }
+                            base = after;
+                        } else if (p[m] > 0.0) {                  // c == 0: fl(0 + p) = p
+                            myev = ((unsigned long long)em << 1) | 0ull;
+                            ev_before = 0.0; ev_p = p[m];
                         }
-                        base = after;
-                    } else if (p[m] > 0.0) {                  // c == 0: fl(0 + p) = p
-                        myev = ((unsigned long long)em << 1) | 0ull;
-                        ev_before = 0.0; ev_p = p[m];
                     }
                 }
             }

@@ -16,6 +16,7 @@
 #include "kmc_hop_lds.h"
 #include "kmc_hop_lds64.h"
 #include "kmc_hop_global.h"
+#include "kmc_hop_big.h"
 
 using namespace kmc;
 
@@ -29,6 +30,9 @@ struct kmc_ctx {
     int device, R, nx, ny, n, window_mode;
     bool lds_path;
     bool lds64;            // 64 x 64 replicas: the specialised kernel of kmc_hop_lds64.h
+    bool big_ok, use_big;  // larger lattices whose bitmaps fit LDS: kmc_hop_big.h (else kmc_hop_global.h)
+    BigGeom geom;
+    double* hier;          // [R][geom.hier_doubles] sum tree of hop_big_kernel (lazy, zeroed once)
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     bool timed;
@@ -484,9 +488,17 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, K64_LDS_BYTES));
         const size_t lds = host_hop_lds_bytes(c->nx, c->n);
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    } else if (nx <= 4096) {
-        const size_t lds = ((sizeof(GbShared) + 15) & ~(size_t)15) + (size_t)nx * 8;
-        CREATE_CHK(hipFuncSetAttribute((const void*)hop_global_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else {
+        if (nx <= 4096) {
+            const size_t lds = ((sizeof(GbShared) + 15) & ~(size_t)15) + (size_t)nx * 8;
+            CREATE_CHK(hipFuncSetAttribute((const void*)hop_global_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        c->big_ok = big_geometry(nx, ny, &c->geom);
+        c->use_big = c->big_ok;
+        if (c->big_ok) {
+            CREATE_CHK(hipFuncSetAttribute((const void*)hop_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->geom.lds_bytes));
+            CREATE_CHK(hipFuncSetAttribute((const void*)hop_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->geom.lds_bytes));
+        }
     }
     CREATE_CHK(hipStreamSynchronize(c->stream));
 #undef CREATE_CHK
@@ -502,7 +514,7 @@ int kmc_destroy(kmc_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* bufs[] = {c->occ, c->keys, c->tags, c->table, c->wsum, c->time_total, c->step_time, c->gamma, c->hist,
-                    c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel, c->w_g, c->tcompact};
+                    c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel, c->w_g, c->tcompact, c->hier};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -555,6 +567,7 @@ int kmc_set_hop_kernel(kmc_ctx* c, int generic)
 {
     CTXCHK(c);
     c->lds64 = c->lds_path && c->nx == 64 && c->ny == 64 && !generic;
+    c->use_big = c->big_ok && !generic;
     return KMC_OK;
 }
 
@@ -835,7 +848,7 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     if (n_hops < 0) return fail(c, KMC_EINVAL, "kmc_run: n_hops < 0");
     if (!c->have_table) return fail(c, KMC_ESTATE, "kmc_run: set a rate table first");
     if (!c->have_keys) return fail(c, KMC_ESTATE, "kmc_run: run kmc_rates_full (or kmc_set_keys) first");
-    if (!c->lds_path && c->nx > 4096)
+    if (!c->lds_path && !c->use_big && c->nx > 4096)
         return fail(c, KMC_EINVAL, "kmc_run: nx = %d exceeds the 4096 rows the global-memory hop kernel keeps in LDS", c->nx);
     if (n_hops == 0) return KMC_OK;
     const size_t Rh = (size_t)c->R * (size_t)n_hops;
@@ -866,6 +879,41 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     // roundings of the kernels' own hierarchical sums (<= 70), np.sum inside a buffer (<= 30), fl(rho * gamma),
     // the 2u of fl(c / gamma) >= rho
     const double mfac = (6.0 * c->n * (1.0 + 1.0 / 8192.0) + 512.0) * ldexp(1.0, -53) * 1.001 * c->margin_scale;
+    if (!c->lds_path && c->use_big) {
+        if (!c->hier) {
+            const size_t bytes = (size_t)c->R * c->geom.hier_doubles * 8;
+            HIPCHK(c, hipMalloc((void**)&c->hier, bytes));
+            HIPCHK(c, hipMemsetAsync(c->hier, 0, bytes, c->stream));
+        }
+        HopBigParams g;
+        memset(&g, 0, sizeof(g));
+        g.g = c->geom; g.window_mode = c->window_mode;
+        g.n_hops = n_hops; g.n_hops_r = dcounts; g.presim = presim != 0; g.force_exact = c->force_exact;
+        g.mfac = mfac;
+        g.table = c->table; g.wsum = c->wsum; g.tcompact = c->tcompact; g.occ = c->occ; g.keys = c->keys; g.hier = c->hier;
+        g.tags = c->tags;
+        g.draws = draws ? c->draws : nullptr; g.sel = sel_out ? c->sel : nullptr;
+        g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32);
+        g.time_total = c->time_total; g.step_time = c->step_time; g.gamma = c->gamma; g.hist = c->hist;
+        g.hops_done = c->hops_done; g.n_exact = c->n_exact; g.status = c->status; g.barrier = c->barrier;
+        const int slot = (int)(c->run_launches % KMC_EV_RING);
+        time_begin(c);
+        HIPCHK(c, hipEventRecord(c->run_ev[slot][0], c->stream));
+        if (c->have_compact)
+            hop_big_kernel<true><<<c->R, KMC_BIG_THREADS, c->geom.lds_bytes, c->stream>>>(g);
+        else
+            hop_big_kernel<false><<<c->R, KMC_BIG_THREADS, c->geom.lds_bytes, c->stream>>>(g);
+        HIPCHK(c, hipEventRecord(c->run_ev[slot][1], c->stream));
+        time_end(c);
+        ++c->run_launches;
+        HIPCHK(c, hipGetLastError());
+        if (sel_out) {
+            HIPCHK(c, hipMemcpyAsync(sel_out, c->sel, Rh * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        if (draws) HIPCHK(c, hipStreamSynchronize(c->stream));
+        return KMC_OK;
+    }
     if (!c->lds_path) {
         if (!c->w_g) HIPCHK(c, hipMalloc((void**)&c->w_g, (size_t)c->R * c->n * 8));
         HopGlobalParams g;

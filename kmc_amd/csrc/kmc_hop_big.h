@@ -1,0 +1,551 @@
+// kmc_hop_big.h -- the hop loop for lattices larger than 64 x 64 whose occupancy bitmaps still
+// fit one CU's LDS (up to ~1.1 M sites: BASELINE config 4, one 1024 x 1024 lattice).
+//
+// Same algorithm as kmc_hop_lds64.h -- hierarchical certified selection, window refresh from
+// bitmaps, drift-free re-sum of what the window touched -- with a deeper hierarchy, because a
+// row is now up to 4096 sites and there are up to 4096 rows.  All sums are trees of 8
+// (group8_sum / row_sum8 association), so every level is a pure function of the level below:
+//
+//   W[key] per site (gathered, never stored)
+//   L1[row][b]   8 sites        L2[row][b]  8 L1        L3[row][8]  8 L2       (global, L2-cache resident)
+//   rowsum[row]  8 L3           R1[g]       8 rows                              (global)
+//   R2[l]        8 R1, one per lane of wave 0, in a register, scanned every hop
+//
+// Workgroup = 256 threads = one lattice.  Wave 0 runs the dependent chain of a hop alone (no
+// barrier inside it): descend R2 -> R1 -> row -> L3 -> L2 -> L1 -> 48 entries, certify, flip two
+// bits, recompute the <= 36 window keys from LDS bitmaps, re-sum the touched blocks from W and
+// climb the tree in registers (children prefetched before the update, DPP trees, ds_bpermute
+// between the 8-lane groups).  Waves 1-3 sleep-poll a sequence number in LDS and join only for
+// the exact path (kmc_exact_par.h), which at 1024 x 1024 is taken by ~0.5 % of the hops: the
+// common hop contains no barrier and no forced wait on its own stores.
+//
+// LDS: column bitmaps with a 2-row / 2-column periodic halo, (ny + 4) x (ceil((nx + 4) / 32) + 1)
+// words (139 808 B at 1024 x 1024); the 5 x 5 neighbourhood of a site is five 2-word reads and
+// five v_alignbit, the periodic wrap being in the halo.
+#pragma once
+#include "kmc_device.h"
+#include "kmc_hop_lds.h"
+#include "kmc_hop_lds64.h"
+#include "kmc_exact_par.h"
+
+namespace kmc {
+
+#define KMC_BIG_THREADS 256
+#define KMC_BIG_VAC 0x7FFFFu                 // table row of a vacant site (all zeros), see K64_VAC
+
+struct BigGeom {
+    int nx, ny, n;
+    int nb1, S1, S2;                         // L1 blocks per row; row strides of L1 (= 8 * nb2) and L2 (= 8 * nb3)
+    int nr1, nr2;                            // R1 groups (ceil(nx / 8)), R2 groups (ceil(nr1 / 8) <= 64)
+    int cw;                                  // words per bitmap column
+    long long offL1, offL2, offL3, offRow, offR1, hier_doubles;   // offsets (in doubles) inside a replica's slab
+    int lds_bytes;
+};
+
+// host + device: layout of a lattice; returns false if this kernel cannot take it
+__host__ __device__ inline bool big_geometry(int nx, int ny, BigGeom* g)
+{
+    g->nx = nx; g->ny = ny; g->n = nx * ny;
+    g->nb1 = (ny + 7) >> 3;
+    const int nb2 = (g->nb1 + 7) >> 3, nb3 = (nb2 + 7) >> 3;
+    g->S1 = nb2 * 8; g->S2 = nb3 * 8;
+    g->nr1 = (nx + 7) >> 3; g->nr2 = (g->nr1 + 7) >> 3;
+    g->cw = ((nx + 4 + 31) >> 5) + 1;
+    long long o = 0;
+    g->offL1 = o; o += (long long)nx * g->S1;
+    g->offL2 = o; o += (long long)nx * g->S2;
+    g->offL3 = o; o += (long long)nx * 8;
+    g->offRow = o; o += (long long)g->nr1 * 8;
+    g->offR1 = o; o += (long long)g->nr2 * 8;
+    g->hier_doubles = o;
+    const long long lds = ((((long long)(ny + 4) * g->cw * 4) + 15) & ~15LL) + 256 + (long long)sizeof(ExactParShared) + 64;
+    g->lds_bytes = (int)lds;
+    return nx >= 5 && ny >= 5 && nb3 <= 8 && g->nr2 <= 64 && lds <= 160 * 1024;
+}
+
+struct HopBigParams {
+    BigGeom g;
+    int window_mode;
+    long long n_hops;
+    const long long* n_hops_r;
+    int presim, force_exact;
+    double mfac;
+    const double* table;
+    const double* wsum;
+    const double* tcompact;
+    uint8_t* occ;
+    uint32_t* keys;
+    double* hier;                // [R][g.hier_doubles], zero-initialised once (the pads stay zero)
+    int4* tags;
+    const double* draws;
+    int32_t* sel;
+    uint32_t seed_lo, seed_hi;
+    double* time_total; double* step_time; double* gamma; long long* hist; long long* hops_done;
+    long long* n_exact; int* status; double* barrier;
+};
+
+struct BigCtrl {                 // wave 0 -> the helper waves
+    int seq, stop;               // seq is bumped for every request; stop = leave
+    double rho;
+    uint32_t kscr[6 * 8];        // new keys of the window, [window row][window column]
+};
+
+template <bool COMPACT>
+__global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const BigGeom g = p.g;
+    const int nx = g.nx, ny = g.ny, n = g.n, cw = g.cw;
+    uint32_t* bm = reinterpret_cast<uint32_t*>(smem);                      // [(ny + 4)][cw]
+    const size_t bm_bytes = (((size_t)(ny + 4) * cw * 4) + 15) & ~(size_t)15;
+    BigCtrl* ctl = reinterpret_cast<BigCtrl*>(smem + bm_bytes);
+    ExactParShared* xp = reinterpret_cast<ExactParShared*>(smem + bm_bytes + 256);
+    static_assert(sizeof(BigCtrl) <= 256, "ctrl block");
+
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint8_t* occ_g = p.occ + (size_t)r * n;
+    uint32_t* keys_g = p.keys + (size_t)r * n;
+    int4* tags_g = p.tags + (size_t)r * n;
+    double* hier = p.hier + (size_t)r * g.hier_doubles;
+    double* L1 = hier + g.offL1;
+    double* L2 = hier + g.offL2;
+    double* L3 = hier + g.offL3;
+    double* rowsum = hier + g.offRow;
+    double* R1 = hier + g.offR1;
+    const double* __restrict__ wsum = p.wsum;
+    const unsigned char* __restrict__ table_b = reinterpret_cast<const unsigned char*>(p.table);
+    const unsigned char* __restrict__ tc_b = reinterpret_cast<const unsigned char*>(p.tcompact);
+    auto wkey = [](uint32_t k) -> uint32_t { return k > 0x3FFFFu ? KMC_BIG_VAC : k; };   // KMC_VACANT -> zero row
+
+    // bit (row rr, column cc) with rr in [-2, nx + 1], cc in [-2, ny + 1]
+    auto bm_word = [&](int rr, int cc) -> int { return (cc + 2) * cw + ((rr + 2) >> 5); };
+    auto bm_flip = [&](int row, int col, bool set) {
+        // the site and its periodic images inside the halo
+        for (int a = 0; a < 2; ++a) {
+            const int rr = a == 0 ? row : (row < 2 ? row + nx : (row >= nx - 2 ? row - nx : -99));
+            if (rr == -99) continue;
+            for (int b = 0; b < 2; ++b) {
+                const int cc = b == 0 ? col : (col < 2 ? col + ny : (col >= ny - 2 ? col - ny : -99));
+                if (cc == -99) continue;
+                const uint32_t bit = 1u << ((rr + 2) & 31);
+                if (set) atomicOr(&bm[bm_word(rr, cc)], bit); else atomicAnd(&bm[bm_word(rr, cc)], ~bit);
+            }
+        }
+    };
+
+    // ---- load: bitmaps from the byte occupancy -------------------------------------------
+    for (int w = tid; w < (ny + 4) * cw; w += KMC_BIG_THREADS) bm[w] = 0u;
+    if (tid == 0) { ctl->seq = 0; ctl->stop = 0; }
+    __syncthreads();
+    for (int s = tid; s < n; s += KMC_BIG_THREADS)
+        if (occ_g[s] & 1u) bm_flip(s / ny, s % ny, true);
+    // ---- the tree, level by level (each parent = row_sum8 of its 8 children) --------------
+    for (long b = tid; b < (long)nx * g.nb1; b += KMC_BIG_THREADS) {
+        const int row = (int)(b / g.nb1), blk = (int)(b % g.nb1);
+        double w[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = blk * 8 + e;
+            w[e] = j < ny ? wsum[wkey(keys_g[(size_t)row * ny + j])] : 0.0;
+        }
+        L1[(size_t)row * g.S1 + blk] = row_sum8(w);
+    }
+    __syncthreads();
+    for (long q = tid; q < (long)nx * (g.S1 >> 3); q += KMC_BIG_THREADS) {
+        const int row = (int)(q / (g.S1 >> 3)), b = (int)(q % (g.S1 >> 3));
+        L2[(size_t)row * g.S2 + b] = row_sum8(L1 + (size_t)row * g.S1 + b * 8);
+    }
+    __syncthreads();
+    for (long q = tid; q < (long)nx * (g.S2 >> 3); q += KMC_BIG_THREADS) {
+        const int row = (int)(q / (g.S2 >> 3)), b = (int)(q % (g.S2 >> 3));
+        L3[(size_t)row * 8 + b] = row_sum8(L2 + (size_t)row * g.S2 + b * 8);
+    }
+    __syncthreads();
+    for (int row = tid; row < nx; row += KMC_BIG_THREADS) rowsum[row] = row_sum8(L3 + (size_t)row * 8);
+    __syncthreads();
+    for (int q = tid; q < g.nr1; q += KMC_BIG_THREADS) R1[q] = row_sum8(rowsum + q * 8);
+    __syncthreads();
+
+    // ---- wave 0 state ------------------------------------------------------------------------
+    double r2 = (wv == 0 && lane < g.nr2) ? row_sum8(R1 + lane * 8) : 0.0;
+    double r2pre = wave_scan_incl(r2);
+    double r2ex = dpp_f64<0x138, 0xF>(r2pre);
+    double gamma = readlane_f64(r2pre, 63);
+
+    int status = 0;
+    long long n_exact = 0, hops = 0;
+    int hist_c = 0;
+    long long hist_v = 0;
+    double time_acc = 0.0;
+    double b_last = p.barrier[r * 5 + 0], b_sum = 0.0, b_min = 1e300, b_max = -1e300, b_cnt = 0.0;
+    const long long hop0 = p.hops_done[r];
+    const long long my_hops = p.n_hops_r ? p.n_hops_r[r] : p.n_hops;
+
+    const int grp_a = lane >> 3, grp_c = lane & 7;
+    const int ent_site = lane < 48 ? (lane * 43) >> 8 : 0;
+    const int ent_dir = lane < 48 ? lane - 6 * ent_site : 0;
+    const uint32_t ent_off = COMPACT ? (uint32_t)ent_dir * (KMC_COMPACT_ROWS * 8u) : (uint32_t)ent_dir * 8u;
+    uint32_t cf_st[5], cf_ln[5], cf_sh[5];
+    {
+        uint32_t m = compact_mask(ent_dir), o = 0;
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            const uint32_t st = m ? (uint32_t)__builtin_ctz(m) : 0u;
+            const uint32_t inv = ~(m >> st);
+            const uint32_t ln = m ? (inv ? (uint32_t)__builtin_ctz(inv) : 32u) : 0u;
+            cf_st[f] = st; cf_ln[f] = ln; cf_sh[f] = o;
+            o += ln;
+            m = ln >= 32u ? 0u : (m & ~(((1u << ln) - 1u) << st));
+        }
+    }
+    const int wm_ext = p.window_mode == 1 ? 0 : 1;
+    const int wm_ni0 = p.window_mode == 0 ? 4 : 5;
+    const int wm_nj0 = p.window_mode == 0 ? 4 : (p.window_mode == 1 ? 6 : 5);
+    const int nslots = (ny & 7) ? 3 : 2;                // L1 blocks a window row can touch
+    const double mfac = p.mfac;
+    const bool force_exact = p.force_exact != 0;
+    const bool presim = p.presim != 0;
+
+    // one level of the descent: 8 children at ch[0..7], running base; returns the child picked
+    auto descend = [&](const double* ch, double t, double& base, bool& ok) -> int {
+        const double sc = scan8_incl(ch[grp_c]);
+        const double bp = base + sc;
+        const double bpe = base + dpp_f64<0x111, 0xF>(sc);
+        const unsigned long long mb = ballot64(bp >= t) & 0xFFull;
+        ok = ok && mb != 0ull;
+        const int q = (__ffsll((long long)mb) - 1) & 7;
+        base = readlane_f64(bpe, q);
+        return q;
+    };
+
+    if (wv != 0) {
+        // ---- helper waves: wait for exact-path requests -------------------------------------------
+        volatile int* vseq = &ctl->seq;
+        volatile int* vstop = &ctl->stop;
+        int seen = 0;
+        for (;;) {
+            int sq;
+            while ((sq = *vseq) == seen) __builtin_amdgcn_s_sleep(16);
+            seen = sq;
+            if (*vstop) break;
+            exact_select_par(keys_g, p.table, n, *(volatile double*)&ctl->rho, xp);
+        }
+    }
+    double rho_v = 0.5, u_v = 1.0, gam_v = 1.0, pn_v = 1.0;
+    int idx_v = -1;
+    int seq_sent = 0;
+    for (long long h = 0; wv == 0 && h < my_hops && status == 0; ++h) {
+        const int hl = (int)(h & 63);
+        int i = 0, j = 0, d = 0;
+        double pnum = 1.0;
+        bool ok = false;
+        if (hl == 0) {
+            // ---- uniforms for the next 64 hops, one hop per lane ---------------------------
+            const int cnt = (int)((my_hops - h) < 64 ? (my_hops - h) : 64);
+            rho_v = 0.5; u_v = 1.0; gam_v = 1.0; pn_v = 1.0; idx_v = -1;
+            if (lane < cnt) {
+                if (p.draws) {
+                    const double2 dv = reinterpret_cast<const double2*>(p.draws)[(size_t)r * p.n_hops + h + lane];
+                    rho_v = dv.x; u_v = dv.y;
+                } else {
+                    const unsigned long long hh = (unsigned long long)(hop0 + h + lane);
+                    u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r; c.w = KMC_STREAM_HOP;
+                    const u32x4 o = philox4x32_10(c, p.seed_lo, p.seed_hi);
+                    rho_v = u53(o.x, o.y); u_v = u53_open0(o.z, o.w);
+                }
+            }
+        }
+        const double rho = readlane_f64(rho_v, hl);
+        {
+            // ---- descent ----------------------------------------------------------------------
+            const double t = rho * gamma;
+            const double M = gamma * mfac;
+            ok = gamma > 0.0 && !force_exact;
+            const unsigned long long m2 = ballot64(r2pre >= t);
+            const int g2 = (__ffsll((long long)m2) - 1) & 63;
+            double base = readlane_f64(r2ex, g2);
+            int g1 = g2 * 8 + descend(R1 + g2 * 8, t, base, ok);
+            if (g1 >= g.nr1) { ok = false; g1 = 0; }
+            i = g1 * 8 + descend(rowsum + g1 * 8, t, base, ok);
+            if (i >= nx) { ok = false; i = 0; }
+            const int b3 = descend(L3 + (size_t)i * 8, t, base, ok);
+            int b2 = b3 * 8 + descend(L2 + (size_t)i * g.S2 + b3 * 8, t, base, ok);
+            if (b2 >= (g.S1 >> 3)) { ok = false; b2 = 0; }
+            int b1 = b2 * 8 + descend(L1 + (size_t)i * g.S1 + b2 * 8, t, base, ok);
+            if (b1 >= g.nb1) { ok = false; b1 = 0; }
+            // ---- entry: 8 sites x 6 directions on 48 lanes ---------------------------------
+            const int ej = b1 * 8 + ent_site;
+            const uint32_t ek = ej < ny ? wkey(keys_g[(size_t)i * ny + ej]) : KMC_BIG_VAC;
+            double rate;
+            if (COMPACT) {
+                uint32_t ci = __builtin_amdgcn_ubfe(ek, cf_st[0], cf_ln[0]);
+#pragma unroll
+                for (int f = 1; f < 5; ++f) ci |= __builtin_amdgcn_ubfe(ek, cf_st[f], cf_ln[f]) << cf_sh[f];
+                rate = *reinterpret_cast<const double*>(tc_b + ((ci << 3) + ent_off));
+            } else {
+                rate = *reinterpret_cast<const double*>(table_b + (ek * 48u + ent_off));
+            }
+            const double esc = wave_scan_incl(rate);
+            const double ap = base + esc;
+            const double ape = base + dpp_f64<0x138, 0xF>(esc);
+            const unsigned long long me = ballot64(ap >= t) & 0xFFFFFFFFFFFFull;
+            const int el = (__ffsll((long long)me) - 1) & 63;
+            const unsigned long long mok = ballot64((ap - t >= M) & (t - ape >= M) & (rate > 0.0));
+            ok = ok && ((me & mok & (0ull - me)) != 0ull);
+            pnum = readlane_f64(rate, el);
+            const int es = (el * 43) >> 8;
+            j = b1 * 8 + es;
+            d = el - 6 * es;
+        }
+        const bool need_exact = !ok;
+        if (need_exact) {
+            // publish the keys this wave stored, wake the helpers, replay the reference together
+            __threadfence_block();
+            if (lane == 0) { *(volatile double*)&ctl->rho = rho; *(volatile int*)&ctl->seq = ++seq_sent; }
+            else ++seq_sent;
+            exact_select_par(keys_g, p.table, n, rho, xp);
+        }
+
+        int exact_flag = 0;
+        if (need_exact) {
+            ++n_exact;
+            const long long idx = xp->idx;
+            const double gx = xp->gamma;
+            if (!(gx > 0.0)) { status = 2; break; }
+            if (idx >= 6LL * n) { status = 1; break; }
+            d = (int)(idx % 6);
+            j = (int)((idx / 6) % ny);
+            i = (int)((idx / 6) / ny);
+            pnum = xp->c_found / gx - xp->cprev_found / gx;       // the reference's own expression (:497)
+            exact_flag = 1 << 30;
+        }
+        // ---- update (:518-535) -----------------------------------------------------------------
+        const int s_src = i * ny + j;
+        const int idx = s_src * 6 + d;
+        const int di = ((2310 >> (2 * d)) & 3) - 1;          // {1, 0, -1, -1, 0, 1}
+        const int dj = ((105 >> (2 * d)) & 3) - 1;           // {0, 1, 1, 0, -1, -1}
+        const int ie = i + di, je = j + dj;                  // unwrapped
+        const int iw = wrap1(ie, nx), jw = wrap1(je, ny);
+        const int s_dst = iw * ny + jw;
+        if (!presim && lane == 0) {                          // tag move (:521-528)
+            int4 tg = tags_g[s_src];
+            tg.z += ie < 0 ? -1 : (ie >= nx ? 1 : 0);
+            tg.w += je < 0 ? -1 : (je >= ny ? 1 : 0);
+            tags_g[s_dst] = tg;
+            tags_g[s_src] = make_int4(-1, 0, 0, 0);
+        }
+        // window geometry (:444-453)
+        const int min_di = di < 0 ? di : 0, min_dj = dj < 0 ? dj : 0;
+        const int i_lo = wrap1(i - 2 + wm_ext * min_di, nx), j_lo = wrap1(j - 2 + wm_ext * min_dj, ny);
+        int n_i = wm_ni0 + wm_ext * (di != 0), n_j = wm_nj0 + wm_ext * (dj != 0);
+        const bool act = grp_a < n_i;
+        const int si = wrap1(i_lo + (act ? grp_a : 0), nx);                // this group's lattice row
+        // the <= 3 L1 blocks the window's columns fall in, cyclically from the block of column j_lo
+        int bs[3];
+        bs[0] = j_lo >> 3;
+        bs[1] = bs[0] + 1 >= g.nb1 ? 0 : bs[0] + 1;
+        bs[2] = bs[1] + 1 >= g.nb1 ? 0 : bs[1] + 1;
+        // ---- reads that do not depend on the update: old keys of the blocks' sites, and the
+        // children of every tree node the window will change
+        uint32_t kold[3];
+        double c1[3], c2[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int cj = bs[q] * 8 + grp_c;
+            kold[q] = (q < nslots && cj < ny) ? keys_g[(size_t)si * ny + cj] : KMC_VACANT;
+            c1[q] = q < nslots ? L1[(size_t)si * g.S1 + (bs[q] >> 3) * 8 + grp_c] : 0.0;      // siblings under its L2 parent
+            c2[q] = q < nslots ? L2[(size_t)si * g.S2 + (bs[q] >> 6) * 8 + grp_c] : 0.0;      // siblings under its L3 parent
+        }
+        double c3 = L3[(size_t)si * 8 + grp_c];
+        // R1 / R2 nodes above the window rows: up to three distinct R1 parents, group k takes the k-th
+        int rp[3], nrp = 0;
+        for (int a = 0; a < n_i; ++a) {
+            const int pr = wrap1(i_lo + a, nx) >> 3;
+            bool seen = false;
+            for (int k = 0; k < nrp; ++k) seen = seen || rp[k] == pr;
+            if (!seen && nrp < 3) rp[nrp++] = pr;
+        }
+        for (int k = nrp; k < 3; ++k) rp[k] = rp[0];
+        const int my_rp = rp[grp_a < 3 ? grp_a : 0];
+        const double crow = rowsum[my_rp * 8 + grp_c];                      // the 8 rows under R1[my_rp]
+        const double cr1 = R1[(my_rp >> 3) * 8 + grp_c];                    // the 8 R1 under R2[my_rp >> 3]
+        // ---- flip the two sites in the bitmaps ---------------------------------------------------
+        if (lane == 0) bm_flip(i, j, false);
+        if (lane == 1) bm_flip(iw, jw, true);
+        hist_c += (lane == d);
+        if (lane == hl) { gam_v = gamma; pn_v = pnum; idx_v = idx | exact_flag; }
+        ++hops;
+        wave_fence();
+        // ---- windowed refresh (:453-465): lane = 8 * (window row) + (window column) ----------
+        if (act && grp_c < n_j) {
+            const int sj = wrap1(j_lo + grp_c, ny);
+            // rows si-2 .. si+2 are bits si .. si+4 of a column; columns sj-2 .. sj+2
+            const uint32_t sh = (uint32_t)si & 31u;
+            const uint32_t* cwp = bm + (size_t)sj * cw + (si >> 5);         // column sj-2 is halo column sj
+            uint32_t win[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) win[q] = __builtin_amdgcn_alignbit(cwp[q * cw + 1], cwp[q * cw], sh);
+            const uint32_t m2 = win[0], m1 = win[1], w0 = win[2], w1 = win[3], w2 = win[4];
+            uint32_t knew = ((w2 & 7u) << 15) | ((w1 & 15u) << 11) | (((w0 >> 3) & 3u) << 9) | ((w0 & 3u) << 7) |
+                            (((m1 >> 1) & 15u) << 3) | ((m2 >> 2) & 7u);
+            knew = (w0 & 4u) ? knew : KMC_VACANT;
+            keys_g[(size_t)si * ny + sj] = knew;
+            ctl->kscr[grp_a * 8 + grp_c] = knew;
+        }
+        wave_fence();
+        // ---- re-sum the touched L1 blocks from W, 8 lanes per block ------------------------------
+        double s1[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double w = 0.0;
+            if (q < nslots && act) {
+                const int cj = bs[q] * 8 + grp_c;
+                int wc = cj - j_lo;
+                if (wc < 0) wc += ny;
+                const uint32_t k = (cj < ny && wc < n_j) ? ctl->kscr[grp_a * 8 + wc] : kold[q];
+                w = wsum[wkey(k)];
+            }
+            s1[q] = group8_sum(w);
+            if (q < nslots && act && grp_c == q) L1[(size_t)si * g.S1 + bs[q]] = s1[q];
+        }
+        // ---- climb: L2, L3, row (each node = tree of its 8 children, the changed ones replaced) ---
+        double s2[3], s3[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double v = c1[q];
+            const int first = (bs[q] >> 3) * 8 + grp_c;                      // L1 index of this lane's child
+#pragma unroll
+            for (int h2 = 0; h2 < 3; ++h2) if (h2 < nslots && first == bs[h2]) v = s1[h2];
+            s2[q] = group8_sum(v);
+            if (q < nslots && act && grp_c == q) L2[(size_t)si * g.S2 + (bs[q] >> 3)] = s2[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double v = c2[q];
+            const int first = (bs[q] >> 6) * 8 + grp_c;                      // L2 index of this lane's child
+#pragma unroll
+            for (int h2 = 0; h2 < 3; ++h2) if (h2 < nslots && first == (bs[h2] >> 3)) v = s2[h2];
+            s3[q] = group8_sum(v);
+            if (q < nslots && act && grp_c == q) L3[(size_t)si * 8 + (bs[q] >> 6)] = s3[q];
+        }
+        {
+#pragma unroll
+            for (int h2 = 0; h2 < 3; ++h2) if (h2 < nslots && grp_c == (bs[h2] >> 6)) c3 = s3[h2];
+        }
+        const double rnew = group8_sum(c3);                                  // new sum of row si (groups a < n_i)
+        if (act && grp_c == 0) rowsum[si] = rnew;
+        // ---- R1: group k < nrp re-sums R1[rp[k]] from its 8 rows ---------------------------------
+        double r1new;
+        {
+            const int rc = my_rp * 8 + grp_c;                                // lattice row of this lane's child
+            int rel = rc - i_lo;
+            if (rel < 0) rel += nx;
+            const int src = (rel & 7) << 5;                                  // lane 8 * rel holds that row's new sum
+            const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(rnew));
+            const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(rnew));
+            const double v = (rc < nx && rel < n_i) ? __hiloint2double(hi, lo) : crow;
+            r1new = group8_sum(v);
+            if (grp_a < nrp && grp_c == 0) R1[my_rp] = r1new;
+        }
+        // ---- R2: the lanes of wave 0 that own a changed R2 node ------------------------------------
+        {
+            double v = cr1;
+            const int first = (my_rp >> 3) * 8 + grp_c;                      // R1 index of this lane's child
+            for (int k = 0; k < nrp; ++k) {
+                const double rk = readlane_f64(r1new, k * 8);
+                if (first == rp[k]) v = rk;
+            }
+            const double r2new = group8_sum(v);                              // group k: new R2[rp[k] >> 3]
+            for (int k = 0; k < nrp; ++k) {
+                const double rk = readlane_f64(r2new, k * 8);
+                if (lane == (rp[k] >> 3)) r2 = rk;
+            }
+        }
+        wave_fence();
+        r2pre = wave_scan_incl(r2);
+        r2ex = dpp_f64<0x138, 0xF>(r2pre);
+        gamma = readlane_f64(r2pre, 63);
+
+        // ---- flush the chunk: clock, trace, barrier diagnostics ------------------------------------
+        if (hl == 63 || h + 1 == my_hops) {
+            const int done = hl + 1;
+            const long long h0 = h - hl;
+            hist_v += hist_c; hist_c = 0;
+            if (!presim) {
+                const double dt = lane < done ? (-1.0 / gam_v) * log(u_v) : 0.0;      // :530
+                time_acc += wave_sum(dt);
+            }
+            if (p.sel && lane < done) p.sel[(size_t)r * p.n_hops + h0 + lane] = idx_v & 0x3FFFFFFF;
+            const bool has = lane < done && (idx_v & 0x3FFFFFFF) != 0;               // :495
+            const double pd_v = (idx_v & (1 << 30)) ? 1.0 : gam_v;
+            const double bar = has ? -log((pn_v / pd_v) / 1e13) * 0.025 : 0.0;      // :496-498
+            const unsigned long long m = __ballot(has);
+            if (m) {
+                b_last = readlane_f64(bar, 63 - __builtin_clzll(m));
+                b_sum += wave_sum(bar);
+                double mn = has ? bar : 1e300, mx = has ? bar : -1e300;
+                for (int off = 32; off > 0; off >>= 1) {
+                    mn = fmin(mn, __shfl_xor(mn, off, 64));
+                    mx = fmax(mx, __shfl_xor(mx, off, 64));
+                }
+                b_min = fmin(b_min, mn); b_max = fmax(b_max, mx);
+                b_cnt += (double)__popcll(m);
+            }
+        }
+    }
+    if (tid == 0) { *(volatile int*)&ctl->stop = 1; *(volatile int*)&ctl->seq = seq_sent + 1; }
+    __syncthreads();
+    // ---- store the lattice (every thread), scalars (wave 0) ------------------------------------------
+    for (int s = tid; s < n; s += KMC_BIG_THREADS) {
+        const int row = s / ny, col = s % ny;
+        occ_g[s] = (uint8_t)((bm[bm_word(row, col)] >> ((row + 2) & 31)) & 1u);
+    }
+    if (wv == 0) {
+        if (status != 0 && hops < my_hops) {
+            // a replica that stopped: records of the unfinished chunk, then the trace of what never ran
+            const int done = (int)(hops & 63);
+            const long long h0 = hops - done;
+            hist_v += hist_c;
+            if (done > 0) {
+                if (!presim) {
+                    const double dt = lane < done ? (-1.0 / gam_v) * log(u_v) : 0.0;
+                    time_acc += wave_sum(dt);
+                }
+                if (p.sel && lane < done) p.sel[(size_t)r * p.n_hops + h0 + lane] = idx_v & 0x3FFFFFFF;
+                const bool has = lane < done && (idx_v & 0x3FFFFFFF) != 0;
+                const double pd_v = (idx_v & (1 << 30)) ? 1.0 : gam_v;
+                const double bar = has ? -log((pn_v / pd_v) / 1e13) * 0.025 : 0.0;
+                const unsigned long long m = __ballot(has);
+                if (m) {
+                    b_last = readlane_f64(bar, 63 - __builtin_clzll(m));
+                    b_sum += wave_sum(bar);
+                    double mn = has ? bar : 1e300, mx = has ? bar : -1e300;
+                    for (int off = 32; off > 0; off >>= 1) {
+                        mn = fmin(mn, __shfl_xor(mn, off, 64));
+                        mx = fmax(mx, __shfl_xor(mx, off, 64));
+                    }
+                    b_min = fmin(b_min, mn); b_max = fmax(b_max, mx);
+                    b_cnt += (double)__popcll(m);
+                }
+            }
+        }
+        if (p.sel)
+            for (long long hh = hops + lane; hh < p.n_hops; hh += 64) p.sel[(size_t)r * p.n_hops + hh] = -1;
+        if (lane < 6) p.hist[r * 6 + lane] += hist_v;
+        if (lane == 0) {
+            p.time_total[r] += time_acc;
+            p.step_time[r] = time_acc;
+            p.gamma[r] = gamma;
+            p.hops_done[r] = hop0 + hops;
+            p.n_exact[r] += n_exact;
+            p.status[r] |= status;
+            p.barrier[r * 5 + 0] = b_last;
+            p.barrier[r * 5 + 1] += b_sum;
+            p.barrier[r * 5 + 2] = fmin(p.barrier[r * 5 + 2], b_min);
+            p.barrier[r * 5 + 3] = fmax(p.barrier[r * 5 + 3], b_max);
+            p.barrier[r * 5 + 4] += b_cnt;
+        }
+    }
+}
+
+}  // namespace kmc

@@ -406,10 +406,15 @@ def test_errors_are_loud(kmc, tables):
     (37, 100, 2, 200, 600, 'full', False, 1.0),
     (130, 70, 2, 200, 800, 'obj_ref', False, 1.0),
     (300, 260, 2, 200, 800, 'hex_ref', False, 1.0),
+    (128, 520, 2, 200, 800, 'full', False, 1.0),
+    (9, 1000, 2, 200, 800, 'hex_ref', False, 1.0),
     (70, 66, 2, 40, 120, 'hex_ref', True, 1.0),
     (90, 90, 2, 200, 600, 'hex_ref', False, 2e6),
 ], ids=lambda c: '%dx%d-%s%s-m%g' % (c[0], c[1], c[5], '-exact' if c[6] else '', c[7]))
-def test_global_memory_kernel_vs_oracle(kmc, tables, dense, cfg):
+@pytest.mark.parametrize('kernel', ['big', 'global'])
+def test_global_memory_kernel_vs_oracle(kmc, tables, dense, cfg, kernel):
+    """Lattices beyond 64 x 64: hop_big_kernel (sum tree in L2, bitmaps in LDS) and the older
+    hop_global_kernel (kept for lattices whose bitmaps do not fit LDS), both against the oracle."""
     nx, ny, R, hp, hs, mode, force, mscale = cfg
     rs = np.random.RandomState(nx + ny)
     conc = np.linspace(0.3, 0.7, R)
@@ -418,6 +423,7 @@ def test_global_memory_kernel_vs_oracle(kmc, tables, dense, cfg):
     d_sim = rs.rand(R, hs, 2)
     with make_engine(kmc, tables, R, nx, ny, mode) as eng:
         assert not eng.uses_lds_path
+        eng.set_hop_kernel(generic=(kernel == 'global'))
         eng.set_debug(force_exact=force, margin_scale=mscale)
         eng.set_lattice(occ)
         eng.rates_full()
