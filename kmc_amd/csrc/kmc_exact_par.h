@@ -33,9 +33,9 @@ namespace kmc {
 
 struct ExactParShared {
     double chunk_sum[KMC_XP_WAVES];
-    long long wave_tot[KMC_XP_WAVES];
+    long long wave_tot[2][KMC_XP_WAVES];     // double-buffered: one barrier per event-free tile
+    int wave_flag[2][KMC_XP_WAVES];
     unsigned long long ev;                   // earliest event of the pass: entry index << 1 | type
-    int any;                                 // some thread of the pass has to look closer
     double c;                                // exact cumsum in front of entry `pos`
     long long pos;
     double gamma, cstar, c_found, cprev_found;
@@ -65,21 +65,27 @@ template <int O>
 __device__ __forceinline__ double xp_leaf128(const uint32_t* __restrict__ keys, const double* __restrict__ table, long lo)
 {
     const long s0 = (lo - O) / 6;
+    uint32_t k[22];
+#pragma unroll
+    for (int q = 0; q < 22; ++q) k[q] = xp_row(keys[s0 + q]);          // 22 loads in flight
     double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool first[8] = {true, true, true, true, true, true, true, true};
 #pragma unroll
-    for (int b = 0; b < 22; b += 4) {                     // batches of 4 sites
-        double v[4][6];
+    for (int b = 0; b < 22; b += 8) {                     // batches of 8 rows, 24 independent 16-byte loads
+        double v[8][6];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
             if (b + q < 22) {
-                const double2* t = reinterpret_cast<const double2*>(table + (size_t)xp_row(keys[s0 + b + q]) * 6);
-                const double2 x = t[0], y = t[1], z = t[2];
+                double2 x = make_double2(0, 0), y = x, z = x;
+                if (k[b + q] != 0x7FFFFu) {                // a vacant site's row is all zeros: no request
+                    const double2* t = reinterpret_cast<const double2*>(table + (size_t)k[b + q] * 6);
+                    x = t[0]; y = t[1]; z = t[2];
+                }
                 v[q][0] = x.x; v[q][1] = x.y; v[q][2] = y.x; v[q][3] = y.y; v[q][4] = z.x; v[q][5] = z.y;
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
 #pragma unroll
             for (int d = 0; d < 6; ++d) {
                 const int e = (b + q) * 6 + d - O;        // position inside the leaf
@@ -93,6 +99,26 @@ __device__ __forceinline__ double xp_leaf128(const uint32_t* __restrict__ keys, 
     return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
 }
 
+// inclusive prefix sum of a 64-bit integer over the wave (DPP, same steps as wave_scan_incl)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_i64(long long x)
+{
+    int lo = (int)x, hi = (int)(x >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, true);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ long long wave_scan_incl_i64(long long x)
+{
+    x += dpp_i64<0x111, 0xF>(x);
+    x += dpp_i64<0x112, 0xF>(x);
+    x += dpp_i64<0x114, 0xF>(x);
+    x += dpp_i64<0x118, 0xF>(x);
+    x += dpp_i64<0x142, 0xA>(x);
+    x += dpp_i64<0x143, 0xC>(x);
+    return x;
+}
+
 // Result in sh->idx, sh->gamma, sh->c_found, sh->cprev_found (every thread may read them after the
 // call; the call ends with a barrier).  keys: KMC_VACANT = vacant; table must have the all-zero row
 // 0x7FFFF (kmc_create allocates 2^19 rows for that).
@@ -100,6 +126,9 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
                                               int n, double rho, ExactParShared* sh)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef KMC_XP_TRACE
+    const unsigned long long xp_t0 = __builtin_amdgcn_s_memtime();
+#endif
     auto entry = [&](long e) -> double {
         const int s = (int)(e / 6);
         const int d = (int)(e - 6 * (long)s);
@@ -150,7 +179,7 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
         }
     }
     __syncthreads();
-    XP_TRACE(0, 1);
+    XP_TRACE(0, 1); XP_TRACE(5, __builtin_amdgcn_s_memtime() - xp_t0);
     if (sh->done) return;
     const double cstar = sh->cstar;
     const long long two53 = 1LL << 53, two54 = 1LL << 54;
@@ -162,28 +191,37 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
         const long s = (long)tid * KMC_XP_SITES + q;
         knext[q] = s < n ? keys[s] : KMC_VACANT;
     }
-    for (long tile0 = 0; tile0 < n6; tile0 += KMC_XP_TILE) {
+    // The running state (c, pos) is uniform and lives in registers: every thread derives it from the
+    // same shared totals.  An event-free tile costs one barrier (wave totals are double-buffered).
+    double c = 0.0;
+    long pos = 0;
+    int parity = 0;
+    bool done = false;
+    const int NE = KMC_XP_SITES * 6;
+    for (long tile0 = 0; tile0 < n6 && !done; tile0 += KMC_XP_TILE) {
         const long tile_end = (tile0 + KMC_XP_TILE) < n6 ? (tile0 + KMC_XP_TILE) : n6;
-        const long e0 = tile0 + (long)tid * (KMC_XP_SITES * 6);
+        const long e0 = tile0 + (long)tid * NE;
         double p[KMC_XP_SITES * 6];
 #pragma unroll
         for (int q = 0; q < KMC_XP_SITES; ++q) {
-            const double2* t = reinterpret_cast<const double2*>(table + (size_t)xp_row(knext[q]) * 6);
-            const double2 a = t[0], b = t[1], c = t[2];
-            p[q * 6 + 0] = a.x; p[q * 6 + 1] = a.y; p[q * 6 + 2] = b.x; p[q * 6 + 3] = b.y; p[q * 6 + 4] = c.x; p[q * 6 + 5] = c.y;
+            double2 a = make_double2(0, 0), b = a, cc = a;
+            if (knext[q] <= 0x3FFFFu) {                        // vacant: zeros, no request
+                const double2* t = reinterpret_cast<const double2*>(table + (size_t)knext[q] * 6);
+                a = t[0]; b = t[1]; cc = t[2];
+            }
+            p[q * 6 + 0] = a.x; p[q * 6 + 1] = a.y; p[q * 6 + 2] = b.x; p[q * 6 + 3] = b.y; p[q * 6 + 4] = cc.x; p[q * 6 + 5] = cc.y;
         }
 #pragma unroll
         for (int q = 0; q < KMC_XP_SITES; ++q) {          // the next tile's keys travel while this one is summed
             const long s = (e0 + KMC_XP_TILE) / 6 + q;
             knext[q] = s < n ? keys[s] : KMC_VACANT;
         }
-        for (;;) {                                        // segments of the tile between events
-            if (tid == 0) { sh->ev = KMC_XP_NOEV; sh->any = 0; }
-            __syncthreads();
-            const double c = sh->c;
-            const long pos = sh->pos;
+        const long hi_l = tile_end - e0;
+        const int hi_m = hi_l < 0 ? 0 : (hi_l > NE ? NE : (int)hi_l);      // my entries [lo_m, hi_m) are live
+        while (pos < tile_end && !done) {                 // segments of the tile between events
             XP_TRACE(1, tile0); XP_TRACE(2, pos); XP_TRACE(3, __double_as_longlong(c)); XP_TRACE(4, g_xp_trace[4] + 1);
-            if (sh->done || pos >= tile_end) break;
+            const long lo_l = pos - e0;
+            const int lo_m = lo_l < 0 ? 0 : (lo_l > NE ? NE : (int)lo_l);
             int ex = 0;
             long long A = 0;
             double scale = 0.0;
@@ -194,59 +232,54 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
                 const double y = pv * scale;              // exact: scale is a power of two
                 const double z = y + magic;
                 const double qd = z - magic;
-                *special = !(y < magic - 1.0) || fabs(qd - y) == 0.5;
+                *special = (!(y < magic - 1.0)) | (fabs(qd - y) == 0.5);
                 return __double_as_longlong(z) & ((1LL << 52) - 1);
             };
-            // pass 1: this thread's integer total and whether it needs a closer look
+            // pass 1 (branch free): this thread's integer total and whether it holds a special entry
             long long run = 0;
             bool flag = false;
             if (c > 0.0) {
 #pragma unroll
-                for (int m = 0; m < KMC_XP_SITES * 6; ++m) {
-                    const long em = e0 + m;
-                    if (em >= pos && em < tile_end) {
-                        bool sp;
-                        const long long q = quantum(p[m], &sp);
-                        flag = flag || sp;
-                        run += q;
-                    }
+                for (int m = 0; m < NE; ++m) {
+                    const bool live = (m >= lo_m) & (m < hi_m);
+                    bool sp;
+                    const long long q = quantum(p[m], &sp);
+                    flag = flag | (sp & live);
+                    run += live ? q : 0LL;
                 }
-                if (flag) run = two54;                    // saturate: everything behind an event is void
+                run = flag ? two54 : run;                 // saturate: everything behind an event is void
             } else {
 #pragma unroll
-                for (int m = 0; m < KMC_XP_SITES * 6; ++m) {
-                    const long em = e0 + m;
-                    flag = flag || (em >= pos && em < tile_end && p[m] > 0.0);
-                }
+                for (int m = 0; m < NE; ++m) flag = flag | ((m >= lo_m) & (m < hi_m) & (p[m] > 0.0));
             }
-            long long incl = run;
-            for (int off = 1; off < 64; off <<= 1) {
-                const long long o = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += o;
-            }
-            if (lane == 63) sh->wave_tot[wv] = incl;
+            const long long incl = wave_scan_incl_i64(run);
+            const bool wflag = __builtin_amdgcn_ballot_w64(flag) != 0ull;
+            if (lane == 63) { sh->wave_tot[parity][wv] = incl; sh->wave_flag[parity][wv] = wflag ? 1 : 0; }
             __syncthreads();
             long long base = A + (incl - run), tot = 0;
+            int anyflag = 0;
 #pragma unroll
             for (int q = 0; q < KMC_XP_WAVES; ++q) {
-                if (q < wv) base += sh->wave_tot[q];
-                tot += sh->wave_tot[q];
+                const long long wt = sh->wave_tot[parity][q];
+                if (q < wv) base += wt;
+                tot += wt;
+                anyflag |= sh->wave_flag[parity][q];
             }
-            if (c > 0.0) {
-                const long long endv = base + run;
-                flag = flag || endv >= two53 || ldexp((double)endv, ex - 52) >= cstar;
-            }
-            if (flag) sh->any = 1;
+            parity ^= 1;
+            const double c_end = c > 0.0 ? ldexp((double)(A + tot), ex - 52) : 0.0;      // exact if no event
+            const bool any = anyflag != 0 || (c > 0.0 && (A + tot >= two53 || c_end >= cstar));
+            if (!any) { c = c_end; pos = tile_end; continue; }           // the common tile
+            // ---- an event somewhere in the tile: find the first one ----------------------------
+            if (tid == 0) sh->ev = KMC_XP_NOEV;
             __syncthreads();
-            const bool any = sh->any != 0;                // false on the common tile: no event, the sum just moves on
-            // pass 2: flagged threads look for their first event
             unsigned long long myev = KMC_XP_NOEV;
             double ev_before = 0.0, ev_after = 0.0, ev_p = 0.0;
-            if (any && flag) {
+            const bool look = flag || (c > 0.0 && (base + run >= two53 || ldexp((double)(base + run), ex - 52) >= cstar));
+            if (look) {
 #pragma unroll
-                for (int m = 0; m < KMC_XP_SITES * 6; ++m) {
-                    const long em = e0 + m;
-                    if (myev == KMC_XP_NOEV && em >= pos && em < tile_end) {
+                for (int m = 0; m < NE; ++m) {
+                    if (myev == KMC_XP_NOEV && m >= lo_m && m < hi_m) {
+                        const long em = e0 + m;
                         if (c > 0.0) {
                             bool sp;
                             const long long q = quantum(p[m], &sp);
@@ -272,12 +305,7 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
             if (myev != KMC_XP_NOEV) atomicMin(&sh->ev, myev);
             __syncthreads();
             const unsigned long long ev = sh->ev;
-            if (ev == KMC_XP_NOEV) {
-                if (tid == 0) {
-                    if (c > 0.0) sh->c = ldexp((double)(A + tot), ex - 52);
-                    sh->pos = tile_end;
-                }
-            } else if (ev == myev) {
+            if (ev != KMC_XP_NOEV && ev == myev) {
                 const long k = (long)(ev >> 1);
                 if (ev & 1ull) {
                     sh->idx = k; sh->c_found = ev_after; sh->cprev_found = ev_before; sh->done = 1;
@@ -288,11 +316,12 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
                 }
             }
             __syncthreads();
+            if (ev == KMC_XP_NOEV) { c = c_end; pos = tile_end; }
+            else { c = sh->c; pos = sh->pos; done = sh->done != 0; }
         }
-        if (sh->done) break;
-        __syncthreads();
     }
     __syncthreads();
+    XP_TRACE(6, __builtin_amdgcn_s_memtime() - xp_t0);
 }
 
 }  // namespace kmc

@@ -889,13 +889,16 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         memset(&g, 0, sizeof(g));
         g.g = c->geom; g.window_mode = c->window_mode;
         g.n_hops = n_hops; g.n_hops_r = dcounts; g.presim = presim != 0; g.force_exact = c->force_exact;
-        g.mfac = mfac;
+        g.mfac = mfac; g.mu = ldexp(1.0, -53) * 1.001 * c->margin_scale;
         g.table = c->table; g.wsum = c->wsum; g.tcompact = c->tcompact; g.occ = c->occ; g.keys = c->keys; g.hier = c->hier;
         g.tags = c->tags;
         g.draws = draws ? c->draws : nullptr; g.sel = sel_out ? c->sel : nullptr;
         g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32);
         g.time_total = c->time_total; g.step_time = c->step_time; g.gamma = c->gamma; g.hist = c->hist;
         g.hops_done = c->hops_done; g.n_exact = c->n_exact; g.status = c->status; g.barrier = c->barrier;
+#ifdef KMC_STAMPS
+        g.stamps = dcounts ? nullptr : reinterpret_cast<long long*>(c->scratch_d);
+#endif
         const int slot = (int)(c->run_launches % KMC_EV_RING);
         time_begin(c);
         HIPCHK(c, hipEventRecord(c->run_ev[slot][0], c->stream));

@@ -8,11 +8,12 @@
 //
 //   W[key] per site (gathered, never stored)
 //   L1[row][b]   8 sites        L2[row][b]  8 L1        L3[row][8]  8 L2       (global, L2-cache resident)
-//   rowsum[row]  8 L3           R1[g]       8 rows                              (global)
+//   rowsum[row]  8 L3           R1[g]       8 rows                              (LDS)
 //   R2[l]        8 R1, one per lane of wave 0, in a register, scanned every hop
 //
 // Workgroup = 256 threads = one lattice.  Wave 0 runs the dependent chain of a hop alone (no
-// barrier inside it): descend R2 -> R1 -> row -> L3 -> L2 -> L1 -> 48 entries, certify, flip two
+// barrier inside it): descend R2 -> 64 rows -> the row's <= 64 L2 nodes -> 8 L1 -> 48 entries (the R1
+// and L3 levels exist for the climb only: a wave-wide scan skips them on the way down), certify, flip two
 // bits, recompute the <= 36 window keys from LDS bitmaps, re-sum the touched blocks from W and
 // climb the tree in registers (children prefetched before the update, DPP trees, ds_bpermute
 // between the 8-lane groups).  Waves 1-3 sleep-poll a sequence number in LDS and join only for
@@ -58,7 +59,8 @@ __host__ __device__ inline bool big_geometry(int nx, int ny, BigGeom* g)
     g->offRow = o; o += (long long)g->nr1 * 8;
     g->offR1 = o; o += (long long)g->nr2 * 8;
     g->hier_doubles = o;
-    const long long lds = ((((long long)(ny + 4) * g->cw * 4) + 15) & ~15LL) + 256 + (long long)sizeof(ExactParShared) + 64;
+    const long long lds = ((((long long)(ny + 4) * g->cw * 4) + 15) & ~15LL) + 256 + (((long long)sizeof(ExactParShared) + 15) & ~15LL) +
+                          ((long long)g->nr1 * 8 + (long long)g->nr2 * 8) * 8 + 64;
     g->lds_bytes = (int)lds;
     return nx >= 5 && ny >= 5 && nb3 <= 8 && g->nr2 <= 64 && lds <= 160 * 1024;
 }
@@ -69,7 +71,8 @@ struct HopBigParams {
     long long n_hops;
     const long long* n_hops_r;
     int presim, force_exact;
-    double mfac;
+    double mfac;                 // unused here (the LDS kernels' flat margin factor)
+    double mu;                   // 2^-53 * 1.001 * margin_scale: unit of the position-dependent margin
     const double* table;
     const double* wsum;
     const double* tcompact;
@@ -82,10 +85,12 @@ struct HopBigParams {
     uint32_t seed_lo, seed_hi;
     double* time_total; double* step_time; double* gamma; long long* hist; long long* hops_done;
     long long* n_exact; int* status; double* barrier;
+    long long* stamps;           // [R][8] cycles per segment (-DKMC_STAMPS builds) or null
 };
 
 struct BigCtrl {                 // wave 0 -> the helper waves
     int seq, stop;               // seq is bumped for every request; stop = leave
+    int n_li;                    // Li atoms of the lattice (conserved)
     double rho;
     uint32_t kscr[6 * 8];        // new keys of the window, [window row][window column]
 };
@@ -101,6 +106,8 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     BigCtrl* ctl = reinterpret_cast<BigCtrl*>(smem + bm_bytes);
     ExactParShared* xp = reinterpret_cast<ExactParShared*>(smem + bm_bytes + 256);
     static_assert(sizeof(BigCtrl) <= 256, "ctrl block");
+    double* rowsum = reinterpret_cast<double*>(smem + bm_bytes + 256 + ((sizeof(ExactParShared) + 15) & ~(size_t)15));   // [nr1 * 8]
+    double* R1 = rowsum + (size_t)g.nr1 * 8;                                                                             // [nr2 * 8]
 
     const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint8_t* occ_g = p.occ + (size_t)r * n;
@@ -110,8 +117,6 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     double* L1 = hier + g.offL1;
     double* L2 = hier + g.offL2;
     double* L3 = hier + g.offL3;
-    double* rowsum = hier + g.offRow;
-    double* R1 = hier + g.offR1;
     const double* __restrict__ wsum = p.wsum;
     const unsigned char* __restrict__ table_b = reinterpret_cast<const unsigned char*>(p.table);
     const unsigned char* __restrict__ tc_b = reinterpret_cast<const unsigned char*>(p.tcompact);
@@ -135,10 +140,12 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
 
     // ---- load: bitmaps from the byte occupancy -------------------------------------------
     for (int w = tid; w < (ny + 4) * cw; w += KMC_BIG_THREADS) bm[w] = 0u;
-    if (tid == 0) { ctl->seq = 0; ctl->stop = 0; }
+    if (tid == 0) { ctl->seq = 0; ctl->stop = 0; ctl->n_li = 0; }
     __syncthreads();
+    int my_li = 0;
     for (int s = tid; s < n; s += KMC_BIG_THREADS)
-        if (occ_g[s] & 1u) bm_flip(s / ny, s % ny, true);
+        if (occ_g[s] & 1u) { bm_flip(s / ny, s % ny, true); ++my_li; }
+    atomicAdd(&ctl->n_li, my_li);
     // ---- the tree, level by level (each parent = row_sum8 of its 8 children) --------------
     for (long b = tid; b < (long)nx * g.nb1; b += KMC_BIG_THREADS) {
         const int row = (int)(b / g.nb1), blk = (int)(b % g.nb1);
@@ -161,11 +168,12 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         L3[(size_t)row * 8 + b] = row_sum8(L2 + (size_t)row * g.S2 + b * 8);
     }
     __syncthreads();
-    for (int row = tid; row < nx; row += KMC_BIG_THREADS) rowsum[row] = row_sum8(L3 + (size_t)row * 8);
+    for (int row = tid; row < g.nr1 * 8; row += KMC_BIG_THREADS) rowsum[row] = row < nx ? row_sum8(L3 + (size_t)row * 8) : 0.0;
     __syncthreads();
-    for (int q = tid; q < g.nr1; q += KMC_BIG_THREADS) R1[q] = row_sum8(rowsum + q * 8);
+    for (int q = tid; q < g.nr2 * 8; q += KMC_BIG_THREADS) R1[q] = q < g.nr1 ? row_sum8(rowsum + q * 8) : 0.0;
     __syncthreads();
 
+    const double six_nli = 6.0 * (double)ctl->n_li;
     // ---- wave 0 state ------------------------------------------------------------------------
     double r2 = (wv == 0 && lane < g.nr2) ? row_sum8(R1 + lane * 8) : 0.0;
     double r2pre = wave_scan_incl(r2);
@@ -202,7 +210,8 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     const int wm_ni0 = p.window_mode == 0 ? 4 : 5;
     const int wm_nj0 = p.window_mode == 0 ? 4 : (p.window_mode == 1 ? 6 : 5);
     const int nslots = (ny & 7) ? 3 : 2;                // L1 blocks a window row can touch
-    const double mfac = p.mfac;
+    const double mu = p.mu;
+    const double xtra = 6.0 * (double)n / 8192.0 + 512.0;
     const bool force_exact = p.force_exact != 0;
     const bool presim = p.presim != 0;
 
@@ -234,6 +243,10 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     double rho_v = 0.5, u_v = 1.0, gam_v = 1.0, pn_v = 1.0;
     int idx_v = -1;
     int seq_sent = 0;
+#ifdef KMC_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
     for (long long h = 0; wv == 0 && h < my_hops && status == 0; ++h) {
         const int hl = (int)(h & 63);
         int i = 0, j = 0, d = 0;
@@ -254,25 +267,44 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
                     rho_v = u53(o.x, o.y); u_v = u53_open0(o.z, o.w);
                 }
             }
+            __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the draws are in; nothing else in the hop waits on them
         }
         const double rho = readlane_f64(rho_v, hl);
+        KMC_STAMP(0);
         {
             // ---- descent ----------------------------------------------------------------------
             const double t = rho * gamma;
-            const double M = gamma * mfac;
             ok = gamma > 0.0 && !force_exact;
             const unsigned long long m2 = ballot64(r2pre >= t);
             const int g2 = (__ffsll((long long)m2) - 1) & 63;
             double base = readlane_f64(r2ex, g2);
-            int g1 = g2 * 8 + descend(R1 + g2 * 8, t, base, ok);
-            if (g1 >= g.nr1) { ok = false; g1 = 0; }
-            i = g1 * 8 + descend(rowsum + g1 * 8, t, base, ok);
-            if (i >= nx) { ok = false; i = 0; }
-            const int b3 = descend(L3 + (size_t)i * 8, t, base, ok);
-            int b2 = b3 * 8 + descend(L2 + (size_t)i * g.S2 + b3 * 8, t, base, ok);
-            if (b2 >= (g.S1 >> 3)) { ok = false; b2 = 0; }
+            // 64 rows of group g2 at once (LDS), then the row's L2 nodes at once (<= 64, one global read)
+            {
+                const int ri = g2 * 64 + lane;
+                const double sc = wave_scan_incl(ri < g.nr1 * 8 ? rowsum[ri] : 0.0);
+                const double bp = base + sc;
+                const double bpe = base + dpp_f64<0x138, 0xF>(sc);
+                const unsigned long long mb = ballot64(bp >= t);
+                ok = ok && mb != 0ull;
+                const int q = (__ffsll((long long)mb) - 1) & 63;
+                base = readlane_f64(bpe, q);
+                i = g2 * 64 + q;
+                if (i >= nx) { ok = false; i = 0; }
+            }
+            int b2;
+            {
+                const double sc = wave_scan_incl(lane < g.S2 ? L2[(size_t)i * g.S2 + lane] : 0.0);
+                const double bp = base + sc;
+                const double bpe = base + dpp_f64<0x138, 0xF>(sc);
+                const unsigned long long mb = ballot64(bp >= t);
+                ok = ok && mb != 0ull;
+                b2 = (__ffsll((long long)mb) - 1) & 63;
+                base = readlane_f64(bpe, b2);
+                if (b2 >= (g.S1 >> 3)) { ok = false; b2 = 0; }
+            }
             int b1 = b2 * 8 + descend(L1 + (size_t)i * g.S1 + b2 * 8, t, base, ok);
             if (b1 >= g.nb1) { ok = false; b1 = 0; }
+            KMC_STAMP(1);
             // ---- entry: 8 sites x 6 directions on 48 lanes ---------------------------------
             const int ej = b1 * 8 + ent_site;
             const uint32_t ek = ej < ny ? wkey(keys_g[(size_t)i * ny + ej]) : KMC_BIG_VAC;
@@ -290,6 +322,13 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             const double ape = base + dpp_f64<0x138, 0xF>(esc);
             const unsigned long long me = ballot64(ap >= t) & 0xFFFFFFFFFFFFull;
             const int el = (__ffsll((long long)me) - 1) & 63;
+            // Margin of THIS entry (kmc_exact_par.h has the flat version's derivation): the reference's
+            // sequential sum has rounded at most m = min(6 (site + 1), 6 N_Li) times when it reaches the
+            // entry (adding a vacant site's zeros is exact), each time by <= u relative to a partial sum
+            // <= ap: m u ap.  Our tree sums (<= 70 roundings), np.sum against our gamma (buffers added left
+            // to right: 6n / 8192 + 30), fl(rho gamma) and the 2u of the quotient are all relative to t <= ap.
+            const double m_add = fmin(6.0 * (double)(i * ny + ej + 1), six_nli);
+            const double M = ap * (mu * (m_add + xtra));
             const unsigned long long mok = ballot64((ap - t >= M) & (t - ape >= M) & (rate > 0.0));
             ok = ok && ((me & mok & (0ull - me)) != 0ull);
             pnum = readlane_f64(rate, el);
@@ -297,6 +336,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             j = b1 * 8 + es;
             d = el - 6 * es;
         }
+        KMC_STAMP(2);
         const bool need_exact = !ok;
         if (need_exact) {
             // publish the keys this wave stored, wake the helpers, replay the reference together
@@ -370,12 +410,25 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         const double crow = rowsum[my_rp * 8 + grp_c];                      // the 8 rows under R1[my_rp]
         const double cr1 = R1[(my_rp >> 3) * 8 + grp_c];                    // the 8 R1 under R2[my_rp >> 3]
         // ---- flip the two sites in the bitmaps ---------------------------------------------------
-        if (lane == 0) bm_flip(i, j, false);
-        if (lane == 1) bm_flip(iw, jw, true);
+        {
+            // lanes 0-3 clear the source bit and its periodic images in the halo, lanes 4-7 set the
+            // destination's: lane & 1 = the row image, lane & 2 = the column image
+            const bool isdst = (lane & 4) != 0;
+            const int row = isdst ? iw : i, col = isdst ? jw : j;
+            const int mr = row < 2 ? row + nx : (row >= nx - 2 ? row - nx : row);
+            const int mc = col < 2 ? col + ny : (col >= ny - 2 ? col - ny : col);
+            const int rr = (lane & 1) ? mr : row, cc = (lane & 2) ? mc : col;
+            const bool valid = (lane < 8) & (!(lane & 1) | (mr != row)) & (!(lane & 2) | (mc != col));
+            const uint32_t bit = 1u << ((rr + 2) & 31);
+            uint32_t* wp = &bm[(cc + 2) * cw + ((rr + 2) >> 5)];
+            if (valid & !isdst) atomicAnd(wp, ~bit);
+            if (valid & isdst) atomicOr(wp, bit);
+        }
         hist_c += (lane == d);
         if (lane == hl) { gam_v = gamma; pn_v = pnum; idx_v = idx | exact_flag; }
         ++hops;
         wave_fence();
+        KMC_STAMP(3);
         // ---- windowed refresh (:453-465): lane = 8 * (window row) + (window column) ----------
         if (act && grp_c < n_j) {
             const int sj = wrap1(j_lo + grp_c, ny);
@@ -393,40 +446,57 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             ctl->kscr[grp_a * 8 + grp_c] = knew;
         }
         wave_fence();
+        KMC_STAMP(4);
         // ---- re-sum the touched L1 blocks from W, 8 lanes per block ------------------------------
-        double s1[3];
+        double s1[3] = {0.0, 0.0, 0.0}, wq[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            double w = 0.0;
+        for (int q = 0; q < 3; ++q) {                                         // all gathers in flight together
             if (q < nslots && act) {
                 const int cj = bs[q] * 8 + grp_c;
                 int wc = cj - j_lo;
                 if (wc < 0) wc += ny;
                 const uint32_t k = (cj < ny && wc < n_j) ? ctl->kscr[grp_a * 8 + wc] : kold[q];
-                w = wsum[wkey(k)];
+                wq[q] = wsum[wkey(k)];
             }
-            s1[q] = group8_sum(w);
-            if (q < nslots && act && grp_c == q) L1[(size_t)si * g.S1 + bs[q]] = s1[q];
         }
+        s1[0] = group8_sum(wq[0]);
+        s1[1] = group8_sum(wq[1]);
+        if (nslots > 2) s1[2] = group8_sum(wq[2]);
+        KMC_STAMP(5);
         // ---- climb: L2, L3, row (each node = tree of its 8 children, the changed ones replaced) ---
-        double s2[3], s3[3];
+        double s2[3] = {0.0, 0.0, 0.0}, s3[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            double v = c1[q];
-            const int first = (bs[q] >> 3) * 8 + grp_c;                      // L1 index of this lane's child
+            if (q < nslots) {
+                double v = c1[q];
+                const int first = (bs[q] >> 3) * 8 + grp_c;                  // L1 index of this lane's child
 #pragma unroll
-            for (int h2 = 0; h2 < 3; ++h2) if (h2 < nslots && first == bs[h2]) v = s1[h2];
-            s2[q] = group8_sum(v);
-            if (q < nslots && act && grp_c == q) L2[(size_t)si * g.S2 + (bs[q] >> 3)] = s2[q];
+                for (int h2 = 0; h2 < 3; ++h2) if (h2 < nslots && first == bs[h2]) v = s1[h2];
+                s2[q] = group8_sum(v);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            double v = c2[q];
-            const int first = (bs[q] >> 6) * 8 + grp_c;                      // L2 index of this lane's child
+            if (q < nslots) {
+                double v = c2[q];
+                const int first = (bs[q] >> 6) * 8 + grp_c;                  // L2 index of this lane's child
 #pragma unroll
-            for (int h2 = 0; h2 < 3; ++h2) if (h2 < nslots && first == (bs[h2] >> 3)) v = s2[h2];
-            s3[q] = group8_sum(v);
-            if (q < nslots && act && grp_c == q) L3[(size_t)si * 8 + (bs[q] >> 6)] = s3[q];
+                for (int h2 = 0; h2 < 3; ++h2) if (h2 < nslots && first == (bs[h2] >> 3)) v = s2[h2];
+                s3[q] = group8_sum(v);
+            }
+        }
+        {
+            // one store instruction for the three levels: lanes 0-2 of a group write L1, 3-5 L2, 6-7 L3
+            // (issuing a vector store costs the wave ~120 cycles whatever its width)
+            const int q = grp_c < 3 ? grp_c : (grp_c < 6 ? grp_c - 3 : grp_c - 6);
+            const int bq = q == 0 ? bs[0] : (q == 1 ? bs[1] : bs[2]);
+            const double v1 = q == 0 ? s1[0] : (q == 1 ? s1[1] : s1[2]);
+            const double v2 = q == 0 ? s2[0] : (q == 1 ? s2[1] : s2[2]);
+            const double v3 = q == 0 ? s3[0] : s3[1];
+            double* ptr = grp_c < 3 ? L1 + (size_t)si * g.S1 + bq
+                        : (grp_c < 6 ? L2 + (size_t)si * g.S2 + (bq >> 3) : L3 + (size_t)si * 8 + (bq >> 6));
+            if (act && q < nslots) *ptr = grp_c < 3 ? v1 : (grp_c < 6 ? v2 : v3);
+            if (nslots > 2 && act && grp_c == 0) L3[(size_t)si * 8 + (bs[2] >> 6)] = s3[2];
         }
         {
 #pragma unroll
@@ -434,6 +504,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         }
         const double rnew = group8_sum(c3);                                  // new sum of row si (groups a < n_i)
         if (act && grp_c == 0) rowsum[si] = rnew;
+        KMC_STAMP(6);
         // ---- R1: group k < nrp re-sums R1[rp[k]] from its 8 rows ---------------------------------
         double r1new;
         {
@@ -465,6 +536,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         r2pre = wave_scan_incl(r2);
         r2ex = dpp_f64<0x138, 0xF>(r2pre);
         gamma = readlane_f64(r2pre, 63);
+        KMC_STAMP(7);
 
         // ---- flush the chunk: clock, trace, barrier diagnostics ------------------------------------
         if (hl == 63 || h + 1 == my_hops) {
@@ -544,6 +616,10 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             p.barrier[r * 5 + 2] = fmin(p.barrier[r * 5 + 2], b_min);
             p.barrier[r * 5 + 3] = fmax(p.barrier[r * 5 + 3], b_max);
             p.barrier[r * 5 + 4] += b_cnt;
+#ifdef KMC_STAMPS
+            if (p.stamps)
+                for (int k = 0; k < 8; ++k) p.stamps[r * 8 + k] = (long long)st_acc[k];
+#endif
         }
     }
 }

@@ -43,6 +43,7 @@ int main(int argc, char** argv)
     // sequential reference
     double c = 0; long idx = 6L * n;
     for (long e = 0; e < 6L * n; ++e) { uint32_t kk = hk[e / 6]; double pv = kk == 0xFFFFFFFFu ? 0.0 : ht[(size_t)kk * 6 + e % 6]; c += pv; if (c / g >= rho) { idx = e; break; } }
+    printf("cycles: np.sum phase %lld, total %lld\n", trace[5], trace[6]);
     printf("gpu idx %lld gamma %.17g c %.17g | cpu idx %ld c %.17g (sequential gamma %.17g) iters %lld %s\n", ho[0], g, *(double*)&ho[2], idx, c, gamma_seq, trace[4],
            (ho[0] == idx && *(double*)&ho[2] == c) ? "MATCH" : "MISMATCH");
     return 0;

@@ -409,6 +409,7 @@ def test_errors_are_loud(kmc, tables):
     (128, 520, 2, 200, 800, 'full', False, 1.0),
     (9, 1000, 2, 200, 800, 'hex_ref', False, 1.0),
     (70, 66, 2, 40, 120, 'hex_ref', True, 1.0),
+    (300, 260, 1, 10, 50, 'hex_ref', True, 1.0),      # exact path over 76 tiles: binade crossings, events
     (90, 90, 2, 200, 600, 'hex_ref', False, 2e6),
 ], ids=lambda c: '%dx%d-%s%s-m%g' % (c[0], c[1], c[5], '-exact' if c[6] else '', c[7]))
 @pytest.mark.parametrize('kernel', ['big', 'global'])
