@@ -15,6 +15,7 @@
 #include "kmc_device.h"
 #include "kmc_hop_lds.h"
 #include "kmc_hop_lds64.h"
+#include "kmc_hop_q64.h"
 #include "kmc_hop_global.h"
 #include "kmc_hop_big.h"
 
@@ -29,7 +30,9 @@ using namespace kmc;
 struct kmc_ctx {
     int device, R, nx, ny, n, window_mode;
     bool lds_path;
-    bool lds64;            // 64 x 64 replicas: the specialised kernel of kmc_hop_lds64.h
+    bool lds64;            // 64 x 64 replicas: the specialised kernels of kmc_hop_lds64.h / kmc_hop_q64.h
+    bool q64;              // ... the 16-replicas-per-CU kernel (kmc_hop_q64.h) rather than the 8-per-CU one
+    void* xscratch;        // [R][Q64_XSCRATCH] exact-path scratch of hop_q64_kernel
     bool big_ok, use_big;  // larger lattices whose bitmaps fit LDS: kmc_hop_big.h (else kmc_hop_global.h)
     BigGeom geom;
     double* hier;          // [R][geom.hier_doubles] sum tree of hop_big_kernel (lazy, zeroed once)
@@ -483,6 +486,8 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     CREATE_CHK(hipMemsetAsync(c->n_exact, 0, c->R * 8, c->stream));
     CREATE_CHK(hipMemsetAsync(c->status, 0, c->R * 4, c->stream));
     c->lds64 = c->lds_path && nx == 64 && ny == 64;
+    c->q64 = c->lds64;
+    if (c->lds64) CREATE_CHK(hipMalloc(&c->xscratch, (size_t)c->R * Q64_XSCRATCH));
     if (c->lds_path) {
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, K64_LDS_BYTES));
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, K64_LDS_BYTES));
@@ -514,7 +519,7 @@ int kmc_destroy(kmc_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* bufs[] = {c->occ, c->keys, c->tags, c->table, c->wsum, c->time_total, c->step_time, c->gamma, c->hist,
-                    c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel, c->w_g, c->tcompact, c->hier};
+                    c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel, c->w_g, c->tcompact, c->hier, c->xscratch};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -560,14 +565,18 @@ int kmc_uses_lds_path(kmc_ctx* c) { return c && c->lds_path ? 1 : 0; }
 int kmc_lds_bytes(kmc_ctx* c)
 {
     if (!c || !c->lds_path) return 0;
-    return c->lds64 ? K64_LDS_BYTES : (int)host_hop_lds_bytes(c->nx, c->n);
+    return c->lds64 ? (c->q64 ? Q64_LDS_BYTES : K64_LDS_BYTES) : (int)host_hop_lds_bytes(c->nx, c->n);
 }
 
-int kmc_set_hop_kernel(kmc_ctx* c, int generic)
+// which = 0: the default kernel for the lattice size; 1: the generic kernel (any size); 2: for 64 x 64
+// replicas, the 8-replicas-per-CU kernel (kmc_hop_lds64.h) instead of the 16-per-CU one (kmc_hop_q64.h)
+int kmc_set_hop_kernel(kmc_ctx* c, int which)
 {
     CTXCHK(c);
-    c->lds64 = c->lds_path && c->nx == 64 && c->ny == 64 && !generic;
-    c->use_big = c->big_ok && !generic;
+    if (which < 0 || which > 2) return fail(c, KMC_EINVAL, "kmc_set_hop_kernel: which must be 0, 1 or 2");
+    c->lds64 = c->lds_path && c->nx == 64 && c->ny == 64 && which != 1;
+    c->q64 = c->lds64 && which == 0;
+    c->use_big = c->big_ok && which != 1;
     return KMC_OK;
 }
 
@@ -963,7 +972,10 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     time_begin(c);
     HIPCHK(c, hipEventRecord(c->run_ev[slot][0], c->stream));
     p.tcompact = c->tcompact;
-    if (c->lds64 && c->have_compact)
+    p.xscratch = c->xscratch;
+    if (c->lds64 && c->q64)
+        hop_q64_kernel<<<c->R, 64, Q64_LDS_BYTES, c->stream>>>(p);
+    else if (c->lds64 && c->have_compact)
         hop_lds64_kernel<true><<<c->R, 64, K64_LDS_BYTES, c->stream>>>(p);
     else if (c->lds64)
         hop_lds64_kernel<false><<<c->R, 64, K64_LDS_BYTES, c->stream>>>(p);

@@ -62,6 +62,7 @@ struct HopParams {
     int* status;                 // [R]
     double* barrier;             // [R][5] last, sum, min, max, count
     long long* stamps;           // [R][8] cycles per segment (-DKMC_STAMPS profiling builds only) or null
+    void* xscratch;              // [R][Q64_XSCRATCH] exact-path scratch of hop_q64_kernel
 };
 
 // Profiling builds (-DKMC_STAMPS, scripts/stamps.py) time the segments of a hop with s_memtime.
@@ -125,7 +126,13 @@ __host__ __device__ inline size_t hop_lds_layout(int nx, int n, size_t* off_blk,
     return o;
 }
 
-__global__ __launch_bounds__(64) void hop_lds_kernel(HopParams p)
+#ifdef KMC_LDS_WAVES            // occupancy experiments only (scripts/probe_occupancy.py)
+#define KMC_LDS_ATTR __attribute__((amdgpu_waves_per_eu(KMC_LDS_WAVES, KMC_LDS_WAVES)))
+#else
+#define KMC_LDS_ATTR
+#endif
+
+__global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int r = blockIdx.x, lane = threadIdx.x;

@@ -1,0 +1,457 @@
+// kmc_hop_q64.h -- the fused hop loop for 64 x 64 replicas at SIXTEEN replicas per CU.
+//
+// hop_lds64_kernel (kmc_hop_lds64.h) is bound by the latency of one wave's dependent chain, and its
+// 17.8 KB of LDS per replica let a CU carry 8 replicas: the vector ALUs are busy 55 % of the time
+// (profiles/r1c_pmc.json) and 4096 replicas per GPU need two rounds.  This kernel runs the same
+// algorithm in 10 032 B of LDS and <= 128 VGPRs, so 16 replicas share a CU (4 waves per SIMD) and
+// the 4096 replicas of the headline configuration are ONE round.  What had to go:
+//   * the block sums (4 KB): lane i keeps the four QUARTER sums of lattice row i (16 sites each) in
+//     registers instead.  quarter = tree8(sites 0-7) + tree8(sites 8-15), row = (Q0+Q1)+(Q2+Q3):
+//     the same association as the block / row sums of the other LDS kernels, so gamma and the
+//     clocks are bit-identical to theirs
+//   * the byte plane of key bits 16-18 (4 KB): bits 16, 17 are packed 2 per site (1 KB, updated with
+//     ds_mskor_b32), and a vacant site is simply key 0x3FFFF (all neighbours Li: every end point
+//     occupied, so its rates are zero in T and W).  Whether a site IS vacant is read from the column
+//     bitmaps when the replica is stored; the hop loop never asks
+//   * the column bitmaps' padding: {lo, hi, lo} = 12 B per column (816 B with the halo columns)
+//   * the exact path's scratch: in global memory (HopParams::xscratch), it runs once in ~1e8 hops
+// Selection is three levels: row (ballot over the per-lane row prefixes), quarter (three compares
+// in the lane that owns the row), entry (16 sites x 6 directions = 2 entries per lane on 48 lanes:
+// ONE 16-byte gather from the dense table per lane, a wave scan of the pair sums).
+#pragma once
+#include "kmc_device.h"
+#include "kmc_hop_lds.h"
+#include "kmc_hop_lds64.h"
+
+namespace kmc {
+
+#define Q64_VAC 0x3FFFFu
+#define Q64_KLO 0
+#define Q64_KHP 8192              // u32[256]: row r = dwords 4r .. 4r+3, site column c = bits 2(c&15) of dword c>>4
+#define Q64_COL 9216              // 12 B x 68: {lo, hi, lo} for columns -2 .. 65
+#define Q64_LDS_BYTES (Q64_COL + 68 * 12)
+#define Q64_XSCRATCH 512          // bytes of global scratch per replica (exact path: 8 frames + the pick)
+#define Q64_WAVES_PER_SIMD 4
+
+static_assert(Q64_LDS_BYTES <= 10240, "16 replicas per CU need <= 10 KB each");
+
+__device__ __forceinline__ uint32_t q64_key(const uint16_t* klo, const uint32_t* khp, int s)
+{
+    return (uint32_t)klo[s] | (((khp[s >> 4] >> ((s & 15) * 2)) & 3u) << 16);
+}
+
+// literal restatement of hex_LiCoO2_kmc.py:486-492, see exact_select() in kmc_hop_lds.h
+__device__ __noinline__ void exact_select_q64(const unsigned char* smem, const double* table, double rho,
+                                              PwFrame* frames, ExactPick* out)
+{
+    const uint16_t* klo = reinterpret_cast<const uint16_t*>(smem + Q64_KLO);
+    const uint32_t* khp = reinterpret_cast<const uint32_t*>(smem + Q64_KHP);
+    auto entry = [&](long e) -> double {
+        const int s = (int)(e / 6);
+        const int d = (int)(e - 6 * (long)s);
+        return table[(size_t)q64_key(klo, khp, s) * 6 + d];
+    };
+    const long n6 = 6L * 4096;
+    const double gamma = np_sum_model(n6, entry, frames);
+    double c = 0., cprev = 0.;
+    long idx = n6;
+    if (0.0 / gamma >= rho) {
+        idx = 0;
+    } else {
+        for (int s = 0; s < 4096 && idx == n6; ++s) {
+            const uint32_t k = q64_key(klo, khp, s);
+            if (k == Q64_VAC) continue;            // a zero row: + 0.0 changes nothing
+            for (int d = 0; d < 6; ++d) {
+                const double pv = table[(size_t)k * 6 + d];
+                if (pv == 0.0) continue;
+                cprev = c;
+                c += pv;
+                if (c / gamma >= rho) { idx = (long)s * 6 + d; break; }
+            }
+        }
+    }
+    out->idx = idx; out->gamma = gamma; out->c = c; out->cprev = cprev;
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Q64_WAVES_PER_SIMD, Q64_WAVES_PER_SIMD)))
+void hop_q64_kernel(HopParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    uint16_t* klo = reinterpret_cast<uint16_t*>(smem + Q64_KLO);
+    uint32_t* khp = reinterpret_cast<uint32_t*>(smem + Q64_KHP);
+    uint32_t* colw = reinterpret_cast<uint32_t*>(smem + Q64_COL);
+    PwFrame* frames = reinterpret_cast<PwFrame*>(reinterpret_cast<unsigned char*>(p.xscratch) + (size_t)r * Q64_XSCRATCH);
+    ExactPick* pick = reinterpret_cast<ExactPick*>(frames + K64_NFRAMES);
+
+    uint8_t* occ_g = p.occ + (size_t)r * 4096;
+    uint32_t* keys_g = p.keys + (size_t)r * 4096;
+    int4* tags_g = p.tags + (size_t)r * 4096;
+    const unsigned char* __restrict__ wsum_b = reinterpret_cast<const unsigned char*>(p.wsum);
+    const unsigned char* __restrict__ table_b = reinterpret_cast<const unsigned char*>(p.table);
+    auto load_w = [&](uint32_t k) -> double {
+        asm("" : "+v"(k));                 // one 32-bit value: keeps k << 3 a 32-bit offset (SGPR base + VGPR offset load)
+        return *reinterpret_cast<const double*>(wsum_b + (k << 3));
+    };
+
+    // ---- load the replica ------------------------------------------------
+    uint64_t cb = 0;                       // lane j owns column j's bitmap
+    for (int i = 0; i < 64; ++i) cb |= (uint64_t)(occ_g[i * 64 + lane] & 1u) << i;
+    // column c lives at dword 3 * (c + 2); columns 0, 1 are mirrored at 64, 65 and 62, 63 at -2, -1
+    const int col_dw = 3 * (lane + 2);
+    const int col_mirror_dw = lane < 2 ? 3 * (lane + 66) : (lane >= 62 ? 3 * (lane - 62) : -1);
+    auto write_col = [&]() {
+        const uint32_t lo = (uint32_t)cb, hi = (uint32_t)(cb >> 32);
+        colw[col_dw] = lo; colw[col_dw + 1] = hi; colw[col_dw + 2] = lo;
+        if (col_mirror_dw >= 0) { colw[col_mirror_dw] = lo; colw[col_mirror_dw + 1] = hi; colw[col_mirror_dw + 2] = lo; }
+    };
+    write_col();
+    for (int s = lane; s < 256; s += KMC_WAVE) khp[s] = 0u;
+    wave_fence();
+    for (int s = lane; s < 4096; s += KMC_WAVE) {
+        uint32_t k = keys_g[s];
+        k = k > 0x3FFFFu ? Q64_VAC : k;    // KMC_VACANT (0xFFFFFFFF) -> all neighbours Li (zero row)
+        klo[s] = (uint16_t)k;
+        atomicOr(&khp[s >> 4], (k >> 16) << ((s & 15) * 2));
+    }
+    wave_fence();
+
+    const int grp_a = lane >> 3, grp_c = lane & 7;     // lane = 8 * a + c
+    double Q0 = 0.0, Q1 = 0.0, Q2 = 0.0, Q3 = 0.0;     // lane i: the quarter sums of row i
+    for (int row = 0; row < 64; ++row) {
+        const double bs = group8_sum(load_w(q64_key(klo, khp, row * 64 + lane)));
+        const double q0 = readlane_f64(bs, 0) + readlane_f64(bs, 8);
+        const double q1 = readlane_f64(bs, 16) + readlane_f64(bs, 24);
+        const double q2 = readlane_f64(bs, 32) + readlane_f64(bs, 40);
+        const double q3 = readlane_f64(bs, 48) + readlane_f64(bs, 56);
+        if (lane == row) { Q0 = q0; Q1 = q1; Q2 = q2; Q3 = q3; }
+    }
+    double rowpre = wave_scan_incl((Q0 + Q1) + (Q2 + Q3));
+    double rowex = dpp_f64<0x138, 0xF>(rowpre);        // exclusive prefix (wave_shr:1, lane 0 <- 0)
+    double gamma = readlane_f64(rowpre, 63);
+
+    int status = 0;
+    long long n_exact = 0, hops = 0;
+    int hist_c = 0;                        // lane d < 6 counts direction d within the launch chunk
+    long long hist_v = 0;
+    double time_acc = 0.0;
+    // barrier statistics: lane 0 = last, 1 = sum, 2 = min, 3 = max, 4 = count (one register pair)
+    double b_stat = lane == 0 ? p.barrier[r * 5 + 0] : (lane == 2 ? 1e300 : (lane == 3 ? -1e300 : 0.0));
+    const long long hop0 = p.hops_done[r];
+
+    // displacement tags: see kmc_hop_lds64.h (moved once per 64-hop chunk)
+    int tg_site = -1, tg_ow = 0, tg_vac = -1;
+    unsigned long long tg_live = 0ull, tg_root = 0ull;
+
+    // entry pick: lane = 3 * (site in quarter) + m, entries 2m and 2m+1 of that site; lanes >= 48 masked out
+    const int ent_site = lane < 48 ? lane / 3 : 0;
+    const int ent_m = lane < 48 ? lane - 3 * ent_site : 0;
+    const uint32_t ent_off = (uint32_t)ent_m * 16u;
+    const uint32_t ent_sh = (uint32_t)ent_site * 2u;
+    // window geometry by mode: i_lo = i - 2 + ext * min(di, 0), n_i = ni0 + ext * |di| (same for j)
+    const int wm_ext = p.window_mode == 1 ? 0 : 1;
+    const int wm_ni0 = p.window_mode == 0 ? 4 : 5;
+    const int wm_nj0 = p.window_mode == 0 ? 4 : (p.window_mode == 1 ? 6 : 5);
+    const double mfac = p.mfac;
+    const bool force_exact = p.force_exact != 0;
+    const bool presim = p.presim != 0;
+
+    const long long my_hops = p.n_hops_r ? p.n_hops_r[r] : p.n_hops;
+#ifdef KMC_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
+    for (long long h0 = 0; h0 < my_hops && status == 0; h0 += KMC_WAVE) {
+        const int cnt = (int)((my_hops - h0) < KMC_WAVE ? (my_hops - h0) : KMC_WAVE);
+        // ---- uniforms for the next 64 hops, one hop per lane --------------
+        double rho_v = 0.5, u_v = 1.0;
+        if (lane < cnt) {
+            if (p.draws) {
+                const double2 dv = reinterpret_cast<const double2*>(p.draws)[(size_t)r * p.n_hops + h0 + lane];
+                rho_v = dv.x; u_v = dv.y;
+            } else {
+                const unsigned long long hh = (unsigned long long)(hop0 + h0 + lane);
+                u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r; c.w = KMC_STREAM_HOP;
+                const u32x4 o = philox4x32_10(c, p.seed_lo, p.seed_hi);
+                rho_v = u53(o.x, o.y); u_v = u53_open0(o.z, o.w);
+            }
+        }
+        double gam_v = 1.0, pn_v = 1.0;    // per-lane record of hop (h0 + lane)
+        int idx_v = -1;                    // bit 30 set: pn_v is already divided (exact path)
+
+        int hl = 0;
+        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the draws are in; nothing in the hop loop waits on them
+        KMC_STAMP(0);
+        for (; hl < cnt; ++hl) {
+            const double t = readlane_f64(rho_v, hl) * gamma;
+            const double M = gamma * mfac;
+            // ---- row ------------------------------------------------------
+            const unsigned long long mr = ballot64(rowpre >= t);
+            const int i = (__ffsll((long long)mr) - 1) & 63;
+            // ---- quarter: every lane decides for its own row, lane i's answer counts ----
+            const double p2 = Q0 + Q1;
+            const double c1 = rowex + Q0, c2 = rowex + p2, c3 = rowex + (p2 + Q2);
+            const int qv = (int)(c1 < t) + (int)(c2 < t) + (int)(c3 < t);
+            const double qbv = c3 < t ? c3 : (c2 < t ? c2 : (c1 < t ? c1 : rowex));
+            const int q = __builtin_amdgcn_readlane(qv, i);
+            const double qbase = readlane_f64(qbv, i);
+            KMC_STAMP(1);
+            // ---- entry: 16 sites x 6 directions, two entries per lane on 48 lanes ----------
+            const uint32_t ek = (uint32_t)klo[i * 64 + q * 16 + ent_site] |
+                                (__builtin_amdgcn_ubfe(khp[i * 4 + q], ent_sh, 2u) << 16);
+            const double2 rr = *reinterpret_cast<const double2*>(table_b + (ek * 48u + ent_off));
+            const double esc = wave_scan_incl(rr.x + rr.y);
+            const double ap = qbase + esc;
+            const double ape = qbase + dpp_f64<0x138, 0xF>(esc);
+            const double a0 = ape + rr.x;
+            const bool first = a0 >= t;
+            const unsigned long long me = ballot64(first | (ap >= t)) & 0xFFFFFFFFFFFFull;
+            const int el = (__ffsll((long long)me) - 1) & 63;
+            const double lo_v = first ? ape : a0, hi_v = first ? a0 : ap, rt_v = first ? rr.x : rr.y;
+            const unsigned long long mok = ballot64((hi_v - t >= M) & (t - lo_v >= M) & (rt_v > 0.0));
+            bool ok = ((me & mok & (0ull - me)) != 0ull) && !force_exact;   // lowest set bit of me certified
+            int j, d, i_sel = i;
+            double pnum = readlane_f64(rt_v, el);
+            int exact_flag = 0;
+            {
+                const int es = el / 3;
+                j = q * 16 + es;
+                d = 2 * (el - 3 * es) + (int)(((ballot64(first) >> el) & 1ull) == 0ull);
+            }
+            if (!ok) {
+                // ---- exact sequential path (rare) --------------------------------
+                wave_fence();
+                exact_select_q64(smem, p.table, readlane_f64(rho_v, hl), frames, pick);
+                wave_fence();
+                ++n_exact;
+                const long idx = pick->idx;
+                const double g = pick->gamma;
+                if (!(g > 0.0)) { status = 2; break; }
+                if (idx >= 6L * 4096) { status = 1; break; }
+                d = (int)(idx % 6);
+                j = (int)((idx / 6) & 63);
+                i_sel = (int)((idx / 6) >> 6);
+                pnum = pick->c / g - pick->cprev / g;      // the reference's own expression (:497)
+                exact_flag = 1 << 30;
+            }
+            KMC_STAMP(2);
+            const int ii = i_sel;
+            const int s_src = ii * 64 + j;
+            const int idx = s_src * 6 + d;
+            // ---- update (:518-535) -------------------------------------------
+            const int di = ((2310 >> (2 * d)) & 3) - 1;          // {1, 0, -1, -1, 0, 1}
+            const int dj = ((105 >> (2 * d)) & 3) - 1;           // {0, 1, 1, 0, -1, -1}
+            const int ie = ii + di, je = j + dj;                 // unwrapped
+            const int iw = ie & 63, jw = je & 63;
+            const int s_dst = iw * 64 + jw;
+            KMC_STAMP(6);
+            // ---- window geometry (:444-453): group a = window row a; its lane c holds sites c and
+            // c + 8 of the one or two quarters the window's columns fall in
+            const int min_di = di < 0 ? di : 0, min_dj = dj < 0 ? dj : 0;
+            const int i_lo = ii - 2 + wm_ext * min_di, n_i = wm_ni0 + wm_ext * (di != 0);
+            const int j_lo = j - 2 + wm_ext * min_dj, n_j = wm_nj0 + wm_ext * (dj != 0);
+            const int si = (i_lo + grp_a) & 63;
+            const bool act = grp_a < n_i;
+            const int qa = (j_lo & 63) >> 4, qb = ((j_lo + n_j - 1) & 63) >> 4;
+            const bool two = qa != qb;                           // uniform
+            // reads that do not depend on the update go first: the keys as they are now (the
+            // window site among them is replaced below)
+            const int sA = si * 64 + qa * 16 + grp_c;
+            const uint32_t hwA = khp[si * 4 + qa];
+            uint32_t kA0 = (uint32_t)klo[sA] | (__builtin_amdgcn_ubfe(hwA, 2u * grp_c, 2u) << 16);
+            uint32_t kA1 = (uint32_t)klo[sA + 8] | (__builtin_amdgcn_ubfe(hwA, 2u * grp_c + 16u, 2u) << 16);
+            uint32_t kB0 = Q64_VAC, kB1 = Q64_VAC;
+            if (two) {
+                const int sB = si * 64 + qb * 16 + grp_c;
+                const uint32_t hwB = khp[si * 4 + qb];
+                kB0 = (uint32_t)klo[sB] | (__builtin_amdgcn_ubfe(hwB, 2u * grp_c, 2u) << 16);
+                kB1 = (uint32_t)klo[sB + 8] | (__builtin_amdgcn_ubfe(hwB, 2u * grp_c + 16u, 2u) << 16);
+            }
+            if (lane == j) cb &= ~(1ull << ii);
+            if (lane == jw) cb |= (1ull << iw);
+            if (lane == j || lane == jw) write_col();
+            wave_fence();
+            KMC_STAMP(7);
+            // ---- windowed refresh (:453-465): this lane's window column is the one = c (mod 8)
+            const int wcol = (grp_c - j_lo) & 7;
+            const int sj = (j_lo + wcol) & 63;
+            const bool inw = act & (wcol < n_j);
+            uint32_t knew;
+            {
+                const int st = (si - 2) & 63;
+                // columns sj-2 .. sj+2 are halo columns sj .. sj+4; +1 dword selects the rotated view
+                const uint32_t ca = lds_base + (uint32_t)(Q64_COL + sj * 12 + (st >> 5) * 4);   // LDS byte address
+                const uint32_t sh = (uint32_t)st & 31u;
+                uint64_t c0, c1, c2, c3, c4;
+                asm volatile("ds_read2_b32 %0, %5 offset1:1\n\t"
+                             "ds_read2_b32 %1, %5 offset0:3 offset1:4\n\t"
+                             "ds_read2_b32 %2, %5 offset0:6 offset1:7\n\t"
+                             "ds_read2_b32 %3, %5 offset0:9 offset1:10\n\t"
+                             "ds_read2_b32 %4, %5 offset0:12 offset1:13\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(c4)
+                             : "v"(ca)
+                             : "memory");
+                const uint32_t m2 = __builtin_amdgcn_alignbit((uint32_t)(c0 >> 32), (uint32_t)c0, sh);
+                const uint32_t m1 = __builtin_amdgcn_alignbit((uint32_t)(c1 >> 32), (uint32_t)c1, sh);
+                const uint32_t w0 = __builtin_amdgcn_alignbit((uint32_t)(c2 >> 32), (uint32_t)c2, sh);
+                const uint32_t w1 = __builtin_amdgcn_alignbit((uint32_t)(c3 >> 32), (uint32_t)c3, sh);
+                const uint32_t w2 = __builtin_amdgcn_alignbit((uint32_t)(c4 >> 32), (uint32_t)c4, sh);
+                knew = ((w2 & 7u) << 15) | ((w1 & 15u) << 11) | (((w0 >> 3) & 3u) << 9) | ((w0 & 3u) << 7) |
+                       (((m1 >> 1) & 15u) << 3) | ((m2 >> 2) & 7u);
+                knew = (w0 & 4u) ? knew : Q64_VAC;
+            }
+            {
+                const bool up = (sj & 8) != 0;                   // the window site is site c + 8 of its quarter
+                const bool inA = inw & ((sj >> 4) == qa);
+                const bool inB = inw & !inA;
+                kA0 = (inA & !up) ? knew : kA0;
+                kA1 = (inA & up) ? knew : kA1;
+                kB0 = (inB & !up) ? knew : kB0;
+                kB1 = (inB & up) ? knew : kB1;
+            }
+            if (inw) {
+                const int s = si * 64 + sj;
+                klo[s] = (uint16_t)knew;
+                const uint32_t fsh = (uint32_t)(sj & 15) * 2u;
+                const uint32_t haddr = lds_base + (uint32_t)(Q64_KHP + (s >> 4) * 4);
+                // MEM = (MEM & ~mask) | value: two key bits of one site inside the quarter's dword
+                asm volatile("ds_mskor_b32 %0, %1, %2" :: "v"(haddr), "v"(3u << fsh), "v"((knew >> 16) << fsh) : "memory");
+            }
+            KMC_STAMP(3);
+            // ---- re-sum the touched quarters (8 lanes per half quarter) and rows -------------
+            double wA0 = 0.0, wA1 = 0.0, wB0 = 0.0, wB1 = 0.0;
+            if (act) { wA0 = load_w(kA0); wA1 = load_w(kA1); }
+            if (two && act) { wB0 = load_w(kB0); wB1 = load_w(kB1); }
+            // ---- book-keeping that nothing in this hop waits for runs while the gathers are in flight
+            hist_c += (lane == d);
+            if (lane == hl) { gam_v = gamma; pn_v = pnum; idx_v = idx | exact_flag; }
+            ++hops;
+            // tag move (:521-528): registers only, memory is touched at the chunk flush
+            if (!presim) {
+                const unsigned long long m = ballot64(tg_site == s_src) & tg_live;
+                // tg_ow = origin lane | (wi + 64) << 8 | (wj + 64) << 16; |w| <= 64 inside a chunk
+                int ow = hl | (64 << 8) | (64 << 16);
+                if (m) {
+                    // the atom came with an earlier hop of this chunk: inherit its origin and wraps
+                    ow = __builtin_amdgcn_readlane(tg_ow, __ffsll((long long)m) - 1);
+                    tg_live &= ~m;
+                } else {
+                    tg_root |= 1ull << hl;                       // its tag is still in memory, at s_src
+                }
+                ow += ((ie >> 6) << 8) + ((je >> 6) << 16);      // wrap: floor(ie / 64) = -1, 0, +1
+                if (lane == hl) { tg_site = s_dst; tg_ow = ow; tg_vac = s_src; }
+                tg_live |= 1ull << hl;
+            }
+            const double sumA = group8_sum(wA0) + group8_sum(wA1);
+            KMC_STAMP(4);
+            {
+                // from group a to the lane that owns row i_lo + a
+                const int rel = (lane - i_lo) & 63;
+                const int src = (rel & 7) << 5;                  // byte address of lane 8 * rel
+                const bool take = rel < n_i;
+                const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(sumA));
+                const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(sumA));
+                const double nA = __hiloint2double(hi, lo);
+                Q0 = (take & (qa == 0)) ? nA : Q0;
+                Q1 = (take & (qa == 1)) ? nA : Q1;
+                Q2 = (take & (qa == 2)) ? nA : Q2;
+                Q3 = (take & (qa == 3)) ? nA : Q3;
+                if (two) {
+                    const double sumB = group8_sum(wB0) + group8_sum(wB1);
+                    const int lob = __builtin_amdgcn_ds_bpermute(src, __double2loint(sumB));
+                    const int hib = __builtin_amdgcn_ds_bpermute(src, __double2hiint(sumB));
+                    const double nB = __hiloint2double(hib, lob);
+                    Q0 = (take & (qb == 0)) ? nB : Q0;
+                    Q1 = (take & (qb == 1)) ? nB : Q1;
+                    Q2 = (take & (qb == 2)) ? nB : Q2;
+                    Q3 = (take & (qb == 3)) ? nB : Q3;
+                }
+            }
+            wave_fence();
+            rowpre = wave_scan_incl((Q0 + Q1) + (Q2 + Q3));
+            rowex = dpp_f64<0x138, 0xF>(rowpre);
+            gamma = readlane_f64(rowpre, 63);
+            KMC_STAMP(5);
+        }
+        // ---- flush the chunk: clock, trace, barrier diagnostics ----------------------
+        const int done = hl;                // hops of this chunk that executed
+        hist_v += hist_c; hist_c = 0;
+        if (!presim && tg_root) {
+            // ---- move the chunk's tags: memory still holds the state before the chunk --------
+            int4 tg_val = make_int4(0, 0, 0, 0);
+            if ((tg_root >> lane) & 1ull) tg_val = tags_g[tg_vac];
+            const bool is_live = (tg_live >> lane) & 1ull;
+            const int site_l = is_live ? tg_site : -1;
+            // a root's home site is vacant now unless a live atom sits on it
+            unsigned long long vac = 0ull;
+            for (unsigned long long rm = tg_root; rm; rm &= rm - 1ull) {
+                const int rl = __ffsll((long long)rm) - 1;
+                const int home = __builtin_amdgcn_readlane(tg_vac, rl);
+                if (ballot64(site_l == home) == 0ull) vac |= 1ull << rl;
+            }
+            const int src = (tg_ow & 63) << 2;
+            int4 tv;
+            tv.x = __builtin_amdgcn_ds_bpermute(src, tg_val.x);
+            tv.y = __builtin_amdgcn_ds_bpermute(src, tg_val.y);
+            tv.z = __builtin_amdgcn_ds_bpermute(src, tg_val.z) + (((tg_ow >> 8) & 255) - 64);
+            tv.w = __builtin_amdgcn_ds_bpermute(src, tg_val.w) + (((tg_ow >> 16) & 255) - 64);
+            if (is_live) tags_g[tg_site] = tv;
+            if ((vac >> lane) & 1ull) tags_g[tg_vac] = make_int4(-1, 0, 0, 0);
+            tg_live = 0ull; tg_root = 0ull; tg_site = -1;
+        }
+        if (!presim) {
+            const double dt = lane < done ? (-1.0 / gam_v) * log(u_v) : 0.0;      // :530
+            time_acc += wave_sum(dt);
+        }
+        if (p.sel && lane < cnt) p.sel[(size_t)r * p.n_hops + h0 + lane] = lane < done ? (idx_v & 0x3FFFFFFF) : -1;
+        {
+            const bool has = lane < done && (idx_v & 0x3FFFFFFF) != 0;           // :495
+            const double pd_v = (idx_v & (1 << 30)) ? 1.0 : gam_v;
+            const double bar = has ? -log((pn_v / pd_v) / 1e13) * 0.025 : 0.0;  // :496-498
+            const unsigned long long m = __ballot(has);
+            if (m) {
+                const double last = readlane_f64(bar, 63 - __builtin_clzll(m));
+                const double sum = wave_sum(bar);
+                double mn = has ? bar : 1e300, mx = has ? bar : -1e300;
+                for (int off = 32; off > 0; off >>= 1) {
+                    mn = fmin(mn, __shfl_xor(mn, off, 64));
+                    mx = fmax(mx, __shfl_xor(mx, off, 64));
+                }
+                b_stat = lane == 0 ? last : (lane == 1 ? b_stat + sum : (lane == 2 ? fmin(b_stat, mn) :
+                         (lane == 3 ? fmax(b_stat, mx) : (lane == 4 ? b_stat + (double)__popcll(m) : b_stat))));
+            }
+        }
+        if (status != 0 && p.sel) {
+            for (long long hh = h0 + KMC_WAVE + lane; hh < p.n_hops; hh += KMC_WAVE)
+                p.sel[(size_t)r * p.n_hops + hh] = -1;
+        }
+    }
+    // ---- store the replica --------------------------------------------------------------
+    wave_fence();
+    for (int i = 0; i < 64; ++i) occ_g[i * 64 + lane] = (uint8_t)((cb >> i) & 1ull);
+    for (int s = lane; s < 4096; s += KMC_WAVE) {
+        // site s = (row s >> 6, column lane): its occupancy is a bit of this lane's own bitmap
+        keys_g[s] = ((cb >> (s >> 6)) & 1ull) ? q64_key(klo, khp, s) : KMC_VACANT;
+    }
+    if (lane < 6) p.hist[r * 6 + lane] += hist_v;
+    if (lane == 0) {
+        p.time_total[r] += time_acc;
+        p.step_time[r] = time_acc;
+        p.gamma[r] = gamma;
+        p.hops_done[r] = hop0 + hops;
+        p.n_exact[r] += n_exact;
+        p.status[r] |= status;
+#ifdef KMC_STAMPS
+        if (p.stamps)
+            for (int k = 0; k < 8; ++k) p.stamps[r * 8 + k] = (long long)st_acc[k];
+#endif
+    }
+    if (lane == 0) p.barrier[r * 5 + 0] = b_stat;
+    if (lane == 1 || lane == 4) p.barrier[r * 5 + lane] += b_stat;
+    if (lane == 2) p.barrier[r * 5 + 2] = fmin(p.barrier[r * 5 + 2], b_stat);
+    if (lane == 3) p.barrier[r * 5 + 3] = fmax(p.barrier[r * 5 + 3], b_stat);
+}
+
+}  // namespace kmc

@@ -235,9 +235,10 @@ class KMCEngine:
         """True if the rate table factors into the compact per-direction table (include/kmc_hip.h)."""
         return bool(self._lib.kmc_table_is_compact(self._ctx))
 
-    def set_hop_kernel(self, generic=False):
-        """64 x 64 replicas: choose the any-size LDS kernel instead of the specialised one (tests)."""
-        self._chk(self._lib.kmc_set_hop_kernel(self._ctx, int(bool(generic))))
+    def set_hop_kernel(self, generic=False, which=None):
+        """Choose the hop kernel (tests): generic=True the any-size kernel; which=2 the 8-replicas-per-CU
+        64 x 64 kernel (kmc_hop_lds64.h) instead of the default 16-per-CU one (kmc_hop_q64.h)."""
+        self._chk(self._lib.kmc_set_hop_kernel(self._ctx, int(which) if which is not None else int(bool(generic))))
 
     def set_debug(self, force_exact=False, margin_scale=1.0):
         self._chk(self._lib.kmc_set_debug(self._ctx, int(bool(force_exact)), float(margin_scale)))
