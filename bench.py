@@ -172,7 +172,7 @@ def main():
                        'hops_per_step': hops_per_step, 'parallelism': 'replicas sharded over %d GPU(s), no data-path collective, one all-reduce of D* accumulators' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'hop_lds64_kernel', 'kernel_ms': k_ms,
+                         'kernel': 'hop_q64_kernel', 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_hop': b_hop, 'hops_per_launch': R * hops_per_step,
                          'note': 'algorithmic bytes are those of the REFERENCE algorithm (full rate-matrix scan per hop); the kernel keeps replica state in LDS and scans hierarchically, so frac > 1 means traffic avoided, not HBM over peak'},
             'kernel_hops_per_s': R * hops_per_step / (k_ms * 1e-3),

@@ -6,9 +6,10 @@
 // algorithm in 10 032 B of LDS and <= 128 VGPRs, so 16 replicas share a CU (4 waves per SIMD) and
 // the 4096 replicas of the headline configuration are ONE round.  What had to go:
 //   * the block sums (4 KB): lane i keeps the four QUARTER sums of lattice row i (16 sites each) in
-//     registers instead.  quarter = tree8(sites 0-7) + tree8(sites 8-15), row = (Q0+Q1)+(Q2+Q3):
-//     the same association as the block / row sums of the other LDS kernels, so gamma and the
-//     clocks are bit-identical to theirs
+//     registers instead.  quarter = tree8 over c of (W[site c] + W[site c + 8]), row = (Q0+Q1)+(Q2+Q3):
+//     a fixed association (every stored sum is a pure function of the keys: no drift, split runs are
+//     bit-identical), but not the block-sum association of the other LDS kernels: gamma and the clocks
+//     agree with theirs to rounding (~1e-16), the selections exactly
 //   * the byte plane of key bits 16-18 (4 KB): bits 16, 17 are packed 2 per site (1 KB, updated with
 //     ds_mskor_b32), and a vacant site is simply key 0x3FFFF (all neighbours Li: every end point
 //     occupied, so its rates are zero in T and W).  Whether a site IS vacant is read from the column
@@ -38,6 +39,23 @@ static_assert(Q64_LDS_BYTES <= 10240, "16 replicas per CU need <= 10 KB each");
 __device__ __forceinline__ uint32_t q64_key(const uint16_t* klo, const uint32_t* khp, int s)
 {
     return (uint32_t)klo[s] | (((khp[s >> 4] >> ((s & 15) * 2)) & 3u) << 16);
+}
+
+// One lane of a VGPR <- a wave-uniform value (v_writelane_b32; this clang has no builtin for it).  The
+// kernel is bound by vector-ALU issue at 4 waves per SIMD, and "if (lane == k) x = uniform" costs a
+// move and a select per dword.  M0 carries the lane number; nothing else in this file uses M0.
+__device__ __forceinline__ void writelane3(int& a, int& b, int& c, int va, int vb, int vc, int lane)
+{
+    asm("s_mov_b32 m0, %6\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\t"
+        "v_writelane_b32 %2, %5, m0"
+        : "+v"(a), "+v"(b), "+v"(c) : "s"(va), "s"(vb), "s"(vc), "s"(lane) : "m0");
+}
+__device__ __forceinline__ void writelane5(int& a, int& b, int& c, int& d, int& e, int va, int vb, int vc, int vd, int ve,
+                                           int lane)
+{
+    asm("s_mov_b32 m0, %10\n\ts_nop 0\n\tv_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\t"
+        "v_writelane_b32 %2, %7, m0\n\tv_writelane_b32 %3, %8, m0\n\tv_writelane_b32 %4, %9, m0"
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "s"(va), "s"(vb), "s"(vc), "s"(vd), "s"(ve), "s"(lane) : "m0");
 }
 
 // literal restatement of hex_LiCoO2_kmc.py:486-492, see exact_select() in kmc_hop_lds.h
@@ -120,11 +138,10 @@ void hop_q64_kernel(HopParams p)
     const int grp_a = lane >> 3, grp_c = lane & 7;     // lane = 8 * a + c
     double Q0 = 0.0, Q1 = 0.0, Q2 = 0.0, Q3 = 0.0;     // lane i: the quarter sums of row i
     for (int row = 0; row < 64; ++row) {
-        const double bs = group8_sum(load_w(q64_key(klo, khp, row * 64 + lane)));
-        const double q0 = readlane_f64(bs, 0) + readlane_f64(bs, 8);
-        const double q1 = readlane_f64(bs, 16) + readlane_f64(bs, 24);
-        const double q2 = readlane_f64(bs, 32) + readlane_f64(bs, 40);
-        const double q3 = readlane_f64(bs, 48) + readlane_f64(bs, 56);
+        // quarter = tree8 over c of (W[site c] + W[site c + 8]): lanes 8..15 of each 16-lane row
+        const double x = load_w(q64_key(klo, khp, row * 64 + lane));
+        const double bs = group8_sum(x + dpp_f64<0x118, 0xF>(x));      // row_shr:8
+        const double q0 = readlane_f64(bs, 8), q1 = readlane_f64(bs, 24), q2 = readlane_f64(bs, 40), q3 = readlane_f64(bs, 56);
         if (lane == row) { Q0 = q0; Q1 = q1; Q2 = q2; Q3 = q3; }
     }
     double rowpre = wave_scan_incl((Q0 + Q1) + (Q2 + Q3));
@@ -133,8 +150,8 @@ void hop_q64_kernel(HopParams p)
 
     int status = 0;
     long long n_exact = 0, hops = 0;
-    int hist_c = 0;                        // lane d < 6 counts direction d within the launch chunk
-    long long hist_v = 0;
+    unsigned long long hist_s = 0ull;      // 6 x 8-bit direction counters of the current chunk (scalar registers)
+    long long hist_v = 0;                  // lane d < 6 counts direction d
     double time_acc = 0.0;
     // barrier statistics: lane 0 = last, 1 = sum, 2 = min, 3 = max, 4 = count (one register pair)
     double b_stat = lane == 0 ? p.barrier[r * 5 + 0] : (lane == 2 ? 1e300 : (lane == 3 ? -1e300 : 0.0));
@@ -177,14 +194,15 @@ void hop_q64_kernel(HopParams p)
                 rho_v = u53(o.x, o.y); u_v = u53_open0(o.z, o.w);
             }
         }
-        double gam_v = 1.0, pn_v = 1.0;    // per-lane record of hop (h0 + lane)
-        int idx_v = -1;                    // bit 30 set: pn_v is already divided (exact path)
+        // per-lane record of hop (h0 + lane): gamma, chosen rate (as dwords, written with v_writelane), index
+        int gam_lo = __double2loint(1.0), gam_hi = __double2hiint(1.0), pn_lo = gam_lo, pn_hi = gam_hi;
+        int idx_v = -1;                    // bit 30 set: pn is already divided (exact path)
 
         int hl = 0;
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the draws are in; nothing in the hop loop waits on them
         KMC_STAMP(0);
         for (; hl < cnt; ++hl) {
-            const double t = readlane_f64(rho_v, hl) * gamma;
+            const double t = readlane_f64(rho_v * gamma, hl);    // one multiply on all lanes: no scalar -> vector moves
             const double M = gamma * mfac;
             // ---- row ------------------------------------------------------
             const unsigned long long mr = ballot64(rowpre >= t);
@@ -192,10 +210,15 @@ void hop_q64_kernel(HopParams p)
             // ---- quarter: every lane decides for its own row, lane i's answer counts ----
             const double p2 = Q0 + Q1;
             const double c1 = rowex + Q0, c2 = rowex + p2, c3 = rowex + (p2 + Q2);
-            const int qv = (int)(c1 < t) + (int)(c2 < t) + (int)(c3 < t);
-            const double qbv = c3 < t ? c3 : (c2 < t ? c2 : (c1 < t ? c1 : rowex));
-            const int q = __builtin_amdgcn_readlane(qv, i);
-            const double qbase = readlane_f64(qbv, i);
+            const unsigned long long b1 = ballot64(c1 < t), b2 = ballot64(c2 < t), b3 = ballot64(c3 < t);
+            const int q = (int)((b1 >> i) & 1ull) + (int)((b2 >> i) & 1ull) + (int)((b3 >> i) & 1ull);
+            double qbase;                  // q is uniform: a branch and one read-lane instead of six selects
+            switch (q) {
+            case 0: asm volatile(""); qbase = readlane_f64(rowex, i); break;
+            case 1: asm volatile(""); qbase = readlane_f64(c1, i); break;
+            case 2: asm volatile(""); qbase = readlane_f64(c2, i); break;
+            default: asm volatile(""); qbase = readlane_f64(c3, i); break;
+            }
             KMC_STAMP(1);
             // ---- entry: 16 sites x 6 directions, two entries per lane on 48 lanes ----------
             const uint32_t ek = (uint32_t)klo[i * 64 + q * 16 + ent_site] |
@@ -206,18 +229,21 @@ void hop_q64_kernel(HopParams p)
             const double ape = qbase + dpp_f64<0x138, 0xF>(esc);
             const double a0 = ape + rr.x;
             const bool first = a0 >= t;
-            const unsigned long long me = ballot64(first | (ap >= t)) & 0xFFFFFFFFFFFFull;
+            const unsigned long long mfirst = ballot64(first);
+            const unsigned long long me = (mfirst | ballot64(ap >= t)) & 0xFFFFFFFFFFFFull;
             const int el = (__ffsll((long long)me) - 1) & 63;
             const double lo_v = first ? ape : a0, hi_v = first ? a0 : ap, rt_v = first ? rr.x : rr.y;
-            const unsigned long long mok = ballot64((hi_v - t >= M) & (t - lo_v >= M) & (rt_v > 0.0));
+            const unsigned long long mok = ballot64(hi_v - t >= M) & ballot64(t - lo_v >= M) & ballot64(rt_v > 0.0);
             bool ok = ((me & mok & (0ull - me)) != 0ull) && !force_exact;   // lowest set bit of me certified
             int j, d, i_sel = i;
-            double pnum = readlane_f64(rt_v, el);
+            // the chosen rate as two scalar dwords (v_writelane takes scalar sources only)
+            int pnum_lo = __builtin_amdgcn_readlane(__double2loint(rt_v), el);
+            int pnum_hi = __builtin_amdgcn_readlane(__double2hiint(rt_v), el);
             int exact_flag = 0;
             {
                 const int es = el / 3;
                 j = q * 16 + es;
-                d = 2 * (el - 3 * es) + (int)(((ballot64(first) >> el) & 1ull) == 0ull);
+                d = 2 * (el - 3 * es) + (int)(((mfirst >> el) & 1ull) == 0ull);
             }
             if (!ok) {
                 // ---- exact sequential path (rare) --------------------------------
@@ -232,7 +258,9 @@ void hop_q64_kernel(HopParams p)
                 d = (int)(idx % 6);
                 j = (int)((idx / 6) & 63);
                 i_sel = (int)((idx / 6) >> 6);
-                pnum = pick->c / g - pick->cprev / g;      // the reference's own expression (:497)
+                const double pn = pick->c / g - pick->cprev / g;      // the reference's own expression (:497)
+                pnum_lo = __builtin_amdgcn_readfirstlane(__double2loint(pn));
+                pnum_hi = __builtin_amdgcn_readfirstlane(__double2hiint(pn));
                 exact_flag = 1 << 30;
             }
             KMC_STAMP(2);
@@ -268,8 +296,10 @@ void hop_q64_kernel(HopParams p)
                 kB0 = (uint32_t)klo[sB] | (__builtin_amdgcn_ubfe(hwB, 2u * grp_c, 2u) << 16);
                 kB1 = (uint32_t)klo[sB + 8] | (__builtin_amdgcn_ubfe(hwB, 2u * grp_c + 16u, 2u) << 16);
             }
-            if (lane == j) cb &= ~(1ull << ii);
-            if (lane == jw) cb |= (1ull << iw);
+            // the source bit is set and the destination bit clear: two flips under exec masks (the
+            // empty asm keeps them branches: as selects they cost four moves and four selects more)
+            if (lane == j) { asm volatile(""); cb ^= 1ull << ii; }
+            if (lane == jw) { asm volatile(""); cb ^= 1ull << iw; }
             if (lane == j || lane == jw) write_col();
             wave_fence();
             KMC_STAMP(7);
@@ -298,18 +328,26 @@ void hop_q64_kernel(HopParams p)
                 const uint32_t w0 = __builtin_amdgcn_alignbit((uint32_t)(c2 >> 32), (uint32_t)c2, sh);
                 const uint32_t w1 = __builtin_amdgcn_alignbit((uint32_t)(c3 >> 32), (uint32_t)c3, sh);
                 const uint32_t w2 = __builtin_amdgcn_alignbit((uint32_t)(c4 >> 32), (uint32_t)c4, sh);
-                knew = ((w2 & 7u) << 15) | ((w1 & 15u) << 11) | (((w0 >> 3) & 3u) << 9) | ((w0 & 3u) << 7) |
-                       (((m1 >> 1) & 15u) << 3) | ((m2 >> 2) & 7u);
-                knew = (w0 & 4u) ? knew : Q64_VAC;
+                knew = __builtin_amdgcn_ubfe(m2, 2u, 3u);
+                knew |= __builtin_amdgcn_ubfe(m1, 1u, 4u) << 3;
+                knew |= ((w0 & 3u) | ((w0 >> 1) & 12u)) << 7;        // window bits 4, 3, 1, 0 (bit 2 is the site itself)
+                knew |= (w1 & 15u) << 11;
+                knew |= (w2 & 7u) << 15;
+                // vacant site -> 0x3FFFF: sign-extended occupancy bit as the select mask of one v_bfi
+                const uint32_t om = (uint32_t)__builtin_amdgcn_sbfe((int)w0, 2u, 1u);
+                knew = (knew & om) | (Q64_VAC & ~om);
             }
             {
-                const bool up = (sj & 8) != 0;                   // the window site is site c + 8 of its quarter
-                const bool inA = inw & ((sj >> 4) == qa);
-                const bool inB = inw & !inA;
-                kA0 = (inA & !up) ? knew : kA0;
-                kA1 = (inA & up) ? knew : kA1;
-                kB0 = (inB & !up) ? knew : kB0;
-                kB1 = (inB & up) ? knew : kB1;
+                // the window site is one of this lane's (up to) four sites: columns cA, cA + 8, cB, cB + 8
+                const int sjw = inw ? sj : -64;
+                const int cA = qa * 16 + grp_c;
+                kA0 = sjw == cA ? knew : kA0;
+                kA1 = sjw == cA + 8 ? knew : kA1;
+                if (two) {
+                    const int cB = qb * 16 + grp_c;
+                    kB0 = sjw == cB ? knew : kB0;
+                    kB1 = sjw == cB + 8 ? knew : kB1;
+                }
             }
             if (inw) {
                 const int s = si * 64 + sj;
@@ -325,8 +363,9 @@ void hop_q64_kernel(HopParams p)
             if (act) { wA0 = load_w(kA0); wA1 = load_w(kA1); }
             if (two && act) { wB0 = load_w(kB0); wB1 = load_w(kB1); }
             // ---- book-keeping that nothing in this hop waits for runs while the gathers are in flight
-            hist_c += (lane == d);
-            if (lane == hl) { gam_v = gamma; pn_v = pnum; idx_v = idx | exact_flag; }
+            hist_s += 1ull << (8 * d);
+            writelane5(gam_lo, gam_hi, pn_lo, pn_hi, idx_v, __double2loint(gamma), __double2hiint(gamma),
+                       pnum_lo, pnum_hi, idx | exact_flag, hl);
             ++hops;
             // tag move (:521-528): registers only, memory is touched at the chunk flush
             if (!presim) {
@@ -341,10 +380,10 @@ void hop_q64_kernel(HopParams p)
                     tg_root |= 1ull << hl;                       // its tag is still in memory, at s_src
                 }
                 ow += ((ie >> 6) << 8) + ((je >> 6) << 16);      // wrap: floor(ie / 64) = -1, 0, +1
-                if (lane == hl) { tg_site = s_dst; tg_ow = ow; tg_vac = s_src; }
+                writelane3(tg_site, tg_ow, tg_vac, s_dst, ow, s_src, hl);
                 tg_live |= 1ull << hl;
             }
-            const double sumA = group8_sum(wA0) + group8_sum(wA1);
+            const double sumA = group8_sum(wA0 + wA1);
             KMC_STAMP(4);
             {
                 // from group a to the lane that owns row i_lo + a
@@ -354,19 +393,24 @@ void hop_q64_kernel(HopParams p)
                 const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(sumA));
                 const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(sumA));
                 const double nA = __hiloint2double(hi, lo);
-                Q0 = (take & (qa == 0)) ? nA : Q0;
-                Q1 = (take & (qa == 1)) ? nA : Q1;
-                Q2 = (take & (qa == 2)) ? nA : Q2;
-                Q3 = (take & (qa == 3)) ? nA : Q3;
+                // qa is uniform: a branch and one select instead of four selects
+                switch (qa) {
+                case 0: asm volatile(""); Q0 = take ? nA : Q0; break;
+                case 1: asm volatile(""); Q1 = take ? nA : Q1; break;
+                case 2: asm volatile(""); Q2 = take ? nA : Q2; break;
+                default: asm volatile(""); Q3 = take ? nA : Q3; break;
+                }
                 if (two) {
-                    const double sumB = group8_sum(wB0) + group8_sum(wB1);
+                    const double sumB = group8_sum(wB0 + wB1);
                     const int lob = __builtin_amdgcn_ds_bpermute(src, __double2loint(sumB));
                     const int hib = __builtin_amdgcn_ds_bpermute(src, __double2hiint(sumB));
                     const double nB = __hiloint2double(hib, lob);
-                    Q0 = (take & (qb == 0)) ? nB : Q0;
-                    Q1 = (take & (qb == 1)) ? nB : Q1;
-                    Q2 = (take & (qb == 2)) ? nB : Q2;
-                    Q3 = (take & (qb == 3)) ? nB : Q3;
+                    switch (qb) {
+                    case 0: asm volatile(""); Q0 = take ? nB : Q0; break;
+                    case 1: asm volatile(""); Q1 = take ? nB : Q1; break;
+                    case 2: asm volatile(""); Q2 = take ? nB : Q2; break;
+                    default: asm volatile(""); Q3 = take ? nB : Q3; break;
+                    }
                 }
             }
             wave_fence();
@@ -377,7 +421,7 @@ void hop_q64_kernel(HopParams p)
         }
         // ---- flush the chunk: clock, trace, barrier diagnostics ----------------------
         const int done = hl;                // hops of this chunk that executed
-        hist_v += hist_c; hist_c = 0;
+        hist_v += (long long)((hist_s >> (8 * (lane & 7))) & 255ull); hist_s = 0ull;
         if (!presim && tg_root) {
             // ---- move the chunk's tags: memory still holds the state before the chunk --------
             int4 tg_val = make_int4(0, 0, 0, 0);
@@ -401,6 +445,7 @@ void hop_q64_kernel(HopParams p)
             if ((vac >> lane) & 1ull) tags_g[tg_vac] = make_int4(-1, 0, 0, 0);
             tg_live = 0ull; tg_root = 0ull; tg_site = -1;
         }
+        const double gam_v = __hiloint2double(gam_hi, gam_lo), pn_v = __hiloint2double(pn_hi, pn_lo);
         if (!presim) {
             const double dt = lane < done ? (-1.0 / gam_v) * log(u_v) : 0.0;      // :530
             time_acc += wave_sum(dt);

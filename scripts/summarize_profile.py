@@ -7,7 +7,7 @@ usage: scripts/summarize_profile.py <tag> [kernel-substring]"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-kern = sys.argv[2] if len(sys.argv) > 2 else 'hop_lds64_kernel'
+kern = sys.argv[2] if len(sys.argv) > 2 else 'hop_q64_kernel'
 src = os.path.join(ROOT, 'gpurun_out', 'prof_' + tag)
 dst = os.path.join(ROOT, 'profiles')
 stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))[0]

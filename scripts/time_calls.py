@@ -2,7 +2,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import kmc_amd
-t = np.load('tests/golden/tables.npz')
+t = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests/golden/tables.npz'))
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 eng = kmc_amd.KMCEngine(R, 64)

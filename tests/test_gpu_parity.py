@@ -252,15 +252,17 @@ def test_random_ensemble_vs_oracle(kmc, tables, dense, cfg):
 # ---------------------------------------------------------------- 64 x 64 kernel vs any-size kernel
 @pytest.mark.parametrize('mode', ['hex_ref', 'obj_ref', 'full'])
 def test_lds64_kernel_equals_generic_kernel(kmc, tables, mode):
-    """The 64 x 64 specialisation keeps every sum's association, so traces, state, gamma and
-    clocks must be bit-identical to the any-size LDS kernel (which the oracle tests above
-    pin), here over 10^6 hops, all concentrations, certified and mixed exact-path modes."""
+    """The 8-per-CU 64 x 64 kernel (kmc_hop_lds64.h) keeps every sum's association, so traces, state,
+    gamma and clocks must be bit-identical to the any-size LDS kernel (which the oracle tests above
+    pin), here over 10^6 hops, all concentrations, certified and mixed exact-path modes.  The default
+    16-per-CU kernel (kmc_hop_q64.h) sums a row's sites in another fixed order: selections, lattices,
+    keys, displacements and histograms are identical, clocks and gamma agree to rounding."""
     R, hp, hs, seed = 72, 4096 + 37, 10000, 0xC0FFEE
     conc = np.repeat(np.linspace(0.1, 0.9, 9), 8)
     out = []
-    for generic in (False, True):
+    for which in (0, 2, 1):                      # default (q64), lds64, generic
         with make_engine(kmc, tables, R, 64, 64, mode) as eng:
-            eng.set_hop_kernel(generic=generic)
+            eng.set_hop_kernel(which=which)
             eng.fill_random(conc, 99)
             eng.rates_full()
             i1 = eng.run(hp, presim=True, seed=seed, want_trace=True)
@@ -269,13 +271,20 @@ def test_lds64_kernel_equals_generic_kernel(kmc, tables, mode):
             eng.set_debug(force_exact=False, margin_scale=2e6)
             i3 = eng.run(300, presim=False, seed=seed, want_trace=True)
             sc, st = eng.scalars(), eng.status()
-            out.append((i1, i2, i3, eng.get_lattice(), eng.get_keys(), eng.get_displacements(), sc['time'],
-                        sc['step_time'], sc['gamma'], sc['hist'], st['n_exact'], st['status'],
+            out.append((i1, i2, i3, eng.get_lattice(), eng.get_keys(), eng.get_displacements(), sc['hist'], st['status'],
+                        sc['time'], sc['step_time'], sc['gamma'], st['n_exact'],
                         np.stack(list(eng.barrier_stats().values()))))
-    for a, b in zip(*out):
+    q64, lds64, generic = out
+    for a, b in zip(lds64, generic):
         assert np.array_equal(a, b)
-    assert out[0][10].sum() > 0 and not out[0][11].any()
-
+    for k in range(8):                           # integer state: exact
+        assert np.array_equal(q64[k], generic[k])
+    for k in (8, 9, 10):                         # clocks, gamma: a different (fixed) summation order
+        np.testing.assert_allclose(q64[k], generic[k], rtol=1e-13)
+    # barrier statistics: the exact path evaluates the reference's cancelling expression (S5), and the
+    # two kernels do not send the same hops through it
+    np.testing.assert_allclose(q64[12], generic[12], rtol=1e-5)
+    assert lds64[11].sum() > 0 and q64[11].sum() > 0 and not q64[7].any()
 
 
 def test_dense_table_that_does_not_factor(kmc, tables, dense):
