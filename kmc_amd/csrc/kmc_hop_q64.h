@@ -58,6 +58,25 @@ __device__ __forceinline__ void writelane5(int& a, int& b, int& c, int& d, int& 
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "s"(va), "s"(vb), "s"(vc), "s"(vd), "s"(ve), "s"(lane) : "m0");
 }
 
+// wave_scan_incl (kmc_device.h) with the two cross-row steps reading into register pairs whose masked
+// rows are zero and stay zero (the DPP move never writes them): saves re-zeroing them, 4 moves a scan.
+// z15 / z31 must be zero in rows {0, 2} / {0, 1} on entry; the other rows are scratch.
+struct ScanZero { int a_lo, a_hi, b_lo, b_hi; };
+__device__ __forceinline__ double wave_scan_incl_z(double x, ScanZero& z)
+{
+    x += dpp_f64<0x111, 0xF>(x);
+    x += dpp_f64<0x112, 0xF>(x);
+    x += dpp_f64<0x114, 0xF>(x);
+    x += dpp_f64<0x118, 0xF>(x);
+    z.a_lo = __builtin_amdgcn_update_dpp(z.a_lo, __double2loint(x), 0x142, 0xA, 0xF, false);
+    z.a_hi = __builtin_amdgcn_update_dpp(z.a_hi, __double2hiint(x), 0x142, 0xA, 0xF, false);
+    x += __hiloint2double(z.a_hi, z.a_lo);
+    z.b_lo = __builtin_amdgcn_update_dpp(z.b_lo, __double2loint(x), 0x143, 0xC, 0xF, false);
+    z.b_hi = __builtin_amdgcn_update_dpp(z.b_hi, __double2hiint(x), 0x143, 0xC, 0xF, false);
+    x += __hiloint2double(z.b_hi, z.b_lo);
+    return x;
+}
+
 // literal restatement of hex_LiCoO2_kmc.py:486-492, see exact_select() in kmc_hop_lds.h
 __device__ __noinline__ void exact_select_q64(const unsigned char* smem, const double* table, double rho,
                                               PwFrame* frames, ExactPick* out)
@@ -144,7 +163,8 @@ void hop_q64_kernel(HopParams p)
         const double q0 = readlane_f64(bs, 8), q1 = readlane_f64(bs, 24), q2 = readlane_f64(bs, 40), q3 = readlane_f64(bs, 56);
         if (lane == row) { Q0 = q0; Q1 = q1; Q2 = q2; Q3 = q3; }
     }
-    double rowpre = wave_scan_incl((Q0 + Q1) + (Q2 + Q3));
+    ScanZero sz = {0, 0, 0, 0};
+    double rowpre = wave_scan_incl_z((Q0 + Q1) + (Q2 + Q3), sz);
     double rowex = dpp_f64<0x138, 0xF>(rowpre);        // exclusive prefix (wave_shr:1, lane 0 <- 0)
     double gamma = readlane_f64(rowpre, 63);
 
@@ -167,7 +187,7 @@ void hop_q64_kernel(HopParams p)
     const uint32_t ent_off = (uint32_t)ent_m * 16u;
     const uint32_t ent_sh = (uint32_t)ent_site * 2u;
     // window geometry by mode: i_lo = i - 2 + ext * min(di, 0), n_i = ni0 + ext * |di| (same for j)
-    const int wm_ext = p.window_mode == 1 ? 0 : 1;
+    const int wm_ext = p.window_mode == 1 ? 0 : -1;    // all-ones mask: the window extends along the hop
     const int wm_ni0 = p.window_mode == 0 ? 4 : 5;
     const int wm_nj0 = p.window_mode == 0 ? 4 : (p.window_mode == 1 ? 6 : 5);
     const double mfac = p.mfac;
@@ -224,7 +244,7 @@ void hop_q64_kernel(HopParams p)
             const uint32_t ek = (uint32_t)klo[i * 64 + q * 16 + ent_site] |
                                 (__builtin_amdgcn_ubfe(khp[i * 4 + q], ent_sh, 2u) << 16);
             const double2 rr = *reinterpret_cast<const double2*>(table_b + (ek * 48u + ent_off));
-            const double esc = wave_scan_incl(rr.x + rr.y);
+            const double esc = wave_scan_incl_z(rr.x + rr.y, sz);
             const double ap = qbase + esc;
             const double ape = qbase + dpp_f64<0x138, 0xF>(esc);
             const double a0 = ape + rr.x;
@@ -232,18 +252,29 @@ void hop_q64_kernel(HopParams p)
             const unsigned long long mfirst = ballot64(first);
             const unsigned long long me = (mfirst | ballot64(ap >= t)) & 0xFFFFFFFFFFFFull;
             const int el = (__ffsll((long long)me) - 1) & 63;
-            const double lo_v = first ? ape : a0, hi_v = first ? a0 : ap, rt_v = first ? rr.x : rr.y;
-            const unsigned long long mok = ballot64(hi_v - t >= M) & ballot64(t - lo_v >= M) & ballot64(rt_v > 0.0);
+            // which of lane el's two entries: uniform, so a branch instead of six selects.  Only bit el
+            // of the certification and lane el's rate are used
+            const bool fst = ((mfirst >> el) & 1ull) != 0ull;
+            unsigned long long mok;
+            int pnum_lo, pnum_hi;          // the chosen rate as two scalar dwords (v_writelane takes scalar sources only)
+            if (fst) {
+                asm volatile("");
+                mok = ballot64(a0 - t >= M) & ballot64(t - ape >= M) & ballot64(rr.x > 0.0);
+                pnum_lo = __builtin_amdgcn_readlane(__double2loint(rr.x), el);
+                pnum_hi = __builtin_amdgcn_readlane(__double2hiint(rr.x), el);
+            } else {
+                asm volatile("");
+                mok = ballot64(ap - t >= M) & ballot64(t - a0 >= M) & ballot64(rr.y > 0.0);
+                pnum_lo = __builtin_amdgcn_readlane(__double2loint(rr.y), el);
+                pnum_hi = __builtin_amdgcn_readlane(__double2hiint(rr.y), el);
+            }
             bool ok = ((me & mok & (0ull - me)) != 0ull) && !force_exact;   // lowest set bit of me certified
             int j, d, i_sel = i;
-            // the chosen rate as two scalar dwords (v_writelane takes scalar sources only)
-            int pnum_lo = __builtin_amdgcn_readlane(__double2loint(rt_v), el);
-            int pnum_hi = __builtin_amdgcn_readlane(__double2hiint(rt_v), el);
             int exact_flag = 0;
             {
                 const int es = el / 3;
                 j = q * 16 + es;
-                d = 2 * (el - 3 * es) + (int)(((mfirst >> el) & 1ull) == 0ull);
+                d = 2 * (el - 3 * es) + (fst ? 0 : 1);
             }
             if (!ok) {
                 // ---- exact sequential path (rare) --------------------------------
@@ -277,25 +308,12 @@ void hop_q64_kernel(HopParams p)
             // ---- window geometry (:444-453): group a = window row a; its lane c holds sites c and
             // c + 8 of the one or two quarters the window's columns fall in
             const int min_di = di < 0 ? di : 0, min_dj = dj < 0 ? dj : 0;
-            const int i_lo = ii - 2 + wm_ext * min_di, n_i = wm_ni0 + wm_ext * (di != 0);
-            const int j_lo = j - 2 + wm_ext * min_dj, n_j = wm_nj0 + wm_ext * (dj != 0);
+            const int i_lo = ii - 2 + (wm_ext & min_di), n_i = wm_ni0 + (wm_ext & di & 1);     // scalar integer ops only
+            const int j_lo = j - 2 + (wm_ext & min_dj), n_j = wm_nj0 + (wm_ext & dj & 1);
             const int si = (i_lo + grp_a) & 63;
             const bool act = grp_a < n_i;
             const int qa = (j_lo & 63) >> 4, qb = ((j_lo + n_j - 1) & 63) >> 4;
             const bool two = qa != qb;                           // uniform
-            // reads that do not depend on the update go first: the keys as they are now (the
-            // window site among them is replaced below)
-            const int sA = si * 64 + qa * 16 + grp_c;
-            const uint32_t hwA = khp[si * 4 + qa];
-            uint32_t kA0 = (uint32_t)klo[sA] | (__builtin_amdgcn_ubfe(hwA, 2u * grp_c, 2u) << 16);
-            uint32_t kA1 = (uint32_t)klo[sA + 8] | (__builtin_amdgcn_ubfe(hwA, 2u * grp_c + 16u, 2u) << 16);
-            uint32_t kB0 = Q64_VAC, kB1 = Q64_VAC;
-            if (two) {
-                const int sB = si * 64 + qb * 16 + grp_c;
-                const uint32_t hwB = khp[si * 4 + qb];
-                kB0 = (uint32_t)klo[sB] | (__builtin_amdgcn_ubfe(hwB, 2u * grp_c, 2u) << 16);
-                kB1 = (uint32_t)klo[sB + 8] | (__builtin_amdgcn_ubfe(hwB, 2u * grp_c + 16u, 2u) << 16);
-            }
             // the source bit is set and the destination bit clear: two flips under exec masks (the
             // empty asm keeps them branches: as selects they cost four moves and four selects more)
             if (lane == j) { asm volatile(""); cb ^= 1ull << ii; }
@@ -337,18 +355,6 @@ void hop_q64_kernel(HopParams p)
                 const uint32_t om = (uint32_t)__builtin_amdgcn_sbfe((int)w0, 2u, 1u);
                 knew = (knew & om) | (Q64_VAC & ~om);
             }
-            {
-                // the window site is one of this lane's (up to) four sites: columns cA, cA + 8, cB, cB + 8
-                const int sjw = inw ? sj : -64;
-                const int cA = qa * 16 + grp_c;
-                kA0 = sjw == cA ? knew : kA0;
-                kA1 = sjw == cA + 8 ? knew : kA1;
-                if (two) {
-                    const int cB = qb * 16 + grp_c;
-                    kB0 = sjw == cB ? knew : kB0;
-                    kB1 = sjw == cB + 8 ? knew : kB1;
-                }
-            }
             if (inw) {
                 const int s = si * 64 + sj;
                 klo[s] = (uint16_t)knew;
@@ -359,9 +365,25 @@ void hop_q64_kernel(HopParams p)
             }
             KMC_STAMP(3);
             // ---- re-sum the touched quarters (8 lanes per half quarter) and rows -------------
-            double wA0 = 0.0, wA1 = 0.0, wB0 = 0.0, wB1 = 0.0;
-            if (act) { wA0 = load_w(kA0); wA1 = load_w(kA1); }
-            if (two && act) { wB0 = load_w(kB0); wB1 = load_w(kB1); }
+            // The lane's sites are read back from LDS after the window's stores (a wave's LDS operations
+            // execute in order): a round trip of latency that the other three waves of the SIMD hide,
+            // instead of ~10 vector instructions deciding which of the lane's keys the window replaced.
+            // Lanes of rows outside the window keep whatever their registers hold: their sums are not used.
+            wave_fence();
+            double wA0, wA1, wB0, wB1;
+            asm("" : "=v"(wA0), "=v"(wA1), "=v"(wB0), "=v"(wB1));
+            if (act) {
+                const int sA = si * 64 + qa * 16 + grp_c;
+                const uint32_t hwA = khp[si * 4 + qa];
+                wA0 = load_w((uint32_t)klo[sA] | (__builtin_amdgcn_ubfe(hwA, 2u * grp_c, 2u) << 16));
+                wA1 = load_w((uint32_t)klo[sA + 8] | (__builtin_amdgcn_ubfe(hwA, 2u * grp_c + 16u, 2u) << 16));
+                if (two) {
+                    const int sB = si * 64 + qb * 16 + grp_c;
+                    const uint32_t hwB = khp[si * 4 + qb];
+                    wB0 = load_w((uint32_t)klo[sB] | (__builtin_amdgcn_ubfe(hwB, 2u * grp_c, 2u) << 16));
+                    wB1 = load_w((uint32_t)klo[sB + 8] | (__builtin_amdgcn_ubfe(hwB, 2u * grp_c + 16u, 2u) << 16));
+                }
+            }
             // ---- book-keeping that nothing in this hop waits for runs while the gathers are in flight
             hist_s += 1ull << (8 * d);
             writelane5(gam_lo, gam_hi, pn_lo, pn_hi, idx_v, __double2loint(gamma), __double2hiint(gamma),
@@ -414,7 +436,7 @@ void hop_q64_kernel(HopParams p)
                 }
             }
             wave_fence();
-            rowpre = wave_scan_incl((Q0 + Q1) + (Q2 + Q3));
+            rowpre = wave_scan_incl_z((Q0 + Q1) + (Q2 + Q3), sz);
             rowex = dpp_f64<0x138, 0xF>(rowpre);
             gamma = readlane_f64(rowpre, 63);
             KMC_STAMP(5);
