@@ -185,6 +185,17 @@ __host__ __device__ inline uint32_t compact_mask(int e)
 }
 #define KMC_COMPACT_BITS 13
 #define KMC_COMPACT_ROWS (1u << KMC_COMPACT_BITS)
+// Pair tables for hop_q64_kernel, whose lanes read the two consecutive entries 2m, 2m+1 of a site with
+// one 16-byte gather: directions 2m and 2m+1 together read 15 key bits.  Pair 1's bits come in four runs;
+// adding key bit 2 (which its rates ignore) joins two of them, so that every pair's index is at most THREE
+// bit-field extracts, at the price of a 16-bit index: Tc2[3][2^16] x {rate 2m, rate 2m+1} = 3 MB allocated,
+// 2 MB touched (pairs 0 and 2 use 2^15 rows each), instead of the 12.6 MB dense table.
+__host__ __device__ inline uint32_t compact2_mask(int m)
+{
+    return compact_mask(2 * m) | compact_mask(2 * m + 1) | (m == 1 ? 4u : 0u);
+}
+#define KMC_COMPACT2_BITS 16
+#define KMC_COMPACT2_ROWS (1u << KMC_COMPACT2_BITS)
 
 __host__ __device__ inline uint32_t pext18(uint32_t key, uint32_t mask)     // slow, table builders only
 {

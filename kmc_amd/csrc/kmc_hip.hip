@@ -48,6 +48,7 @@ struct kmc_ctx {
     double* table;
     double* wsum;
     double* tcompact;      // [6][2^13] per-direction compact table, valid if have_compact
+    double* tcompact2;     // [3][2^16][2] pair tables (kmc_device.h), valid if have_compact
     bool have_compact;
     double* time_total;
     double* step_time;
@@ -136,6 +137,16 @@ __global__ __launch_bounds__(256) void compact_build_kernel(const double* __rest
     const int e = (int)(t >> KMC_COMPACT_BITS);
     const uint32_t idx = t & (KMC_COMPACT_ROWS - 1);
     tc[t] = table[(size_t)pdep18(idx, compact_mask(e)) * 6 + e];
+}
+
+__global__ __launch_bounds__(256) void compact2_build_kernel(const double* __restrict__ table, double* __restrict__ tc2)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;            // [3][2^15]
+    const int m = (int)(t >> KMC_COMPACT2_BITS);
+    const uint32_t idx = t & (KMC_COMPACT2_ROWS - 1);
+    const size_t row = (size_t)pdep18(idx, compact2_mask(m)) * 6;
+    tc2[2 * (size_t)t] = table[row + 2 * m];
+    tc2[2 * (size_t)t + 1] = table[row + 2 * m + 1];
 }
 
 __global__ __launch_bounds__(256) void compact_verify_kernel(const double* __restrict__ table, const double* __restrict__ tc,
@@ -466,6 +477,7 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     CREATE_CHK(hipMemsetAsync(c->table + (size_t)(2 * KMC_TABLE_ROWS - 1) * 6, 0, 48, c->stream));
     CREATE_CHK(hipMemsetAsync(c->wsum + (2 * KMC_TABLE_ROWS - 1), 0, 8, c->stream));
     CREATE_CHK(hipMalloc((void**)&c->tcompact, (size_t)6 * KMC_COMPACT_ROWS * 8));
+    CREATE_CHK(hipMalloc((void**)&c->tcompact2, (size_t)3 * KMC_COMPACT2_ROWS * 16));
     CREATE_CHK(hipMalloc((void**)&c->time_total, c->R * 8));
     CREATE_CHK(hipMalloc((void**)&c->step_time, c->R * 8));
     CREATE_CHK(hipMalloc((void**)&c->gamma, c->R * 8));
@@ -519,7 +531,7 @@ int kmc_destroy(kmc_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* bufs[] = {c->occ, c->keys, c->tags, c->table, c->wsum, c->time_total, c->step_time, c->gamma, c->hist,
-                    c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel, c->w_g, c->tcompact, c->hier, c->xscratch};
+                    c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel, c->w_g, c->tcompact, c->tcompact2, c->hier, c->xscratch};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -586,6 +598,8 @@ static int build_compact(kmc_ctx* c)
     int* flag = reinterpret_cast<int*>(c->scratch_d);
     HIPCHK(c, hipMemsetAsync(flag, 0, 4, c->stream));
     compact_build_kernel<<<6 * KMC_COMPACT_ROWS / 256, 256, 0, c->stream>>>(c->table, c->tcompact);
+    // the pair tables need no check of their own: a rate that reads 13 key bits reads the pair's 15
+    compact2_build_kernel<<<3 * KMC_COMPACT2_ROWS / 256, 256, 0, c->stream>>>(c->table, c->tcompact2);
     compact_verify_kernel<<<KMC_TABLE_ROWS / 256, 256, 0, c->stream>>>(c->table, c->tcompact, flag);
     HIPCHK(c, hipGetLastError());
     int bad = 0;
@@ -973,8 +987,15 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     HIPCHK(c, hipEventRecord(c->run_ev[slot][0], c->stream));
     p.tcompact = c->tcompact;
     p.xscratch = c->xscratch;
-    if (c->lds64 && c->q64)
-        hop_q64_kernel<<<c->R, 64, Q64_LDS_BYTES, c->stream>>>(p);
+    p.tcompact2 = c->tcompact2;
+#ifdef Q64_FORCE_DENSE          // scripts/variants.py: A/B of the pair tables against the dense table
+    if (false)
+#else
+    if (c->lds64 && c->q64 && c->have_compact)
+#endif
+        hop_q64_kernel<true><<<c->R, 64, Q64_LDS_BYTES, c->stream>>>(p);
+    else if (c->lds64 && c->q64)
+        hop_q64_kernel<false><<<c->R, 64, Q64_LDS_BYTES, c->stream>>>(p);
     else if (c->lds64 && c->have_compact)
         hop_lds64_kernel<true><<<c->R, 64, K64_LDS_BYTES, c->stream>>>(p);
     else if (c->lds64)

@@ -63,6 +63,7 @@ struct HopParams {
     double* barrier;             // [R][5] last, sum, min, max, count
     long long* stamps;           // [R][8] cycles per segment (-DKMC_STAMPS profiling builds only) or null
     void* xscratch;              // [R][Q64_XSCRATCH] exact-path scratch of hop_q64_kernel
+    const double* tcompact2;     // [3][2^15][2] pair tables (hop_q64_kernel<true>) or null
 };
 
 // Profiling builds (-DKMC_STAMPS, scripts/stamps.py) time the segments of a hop with s_memtime.

@@ -44,11 +44,10 @@ __device__ __forceinline__ uint32_t q64_key(const uint16_t* klo, const uint32_t*
 // One lane of a VGPR <- a wave-uniform value (v_writelane_b32; this clang has no builtin for it).  The
 // kernel is bound by vector-ALU issue at 4 waves per SIMD, and "if (lane == k) x = uniform" costs a
 // move and a select per dword.  M0 carries the lane number; nothing else in this file uses M0.
-__device__ __forceinline__ void writelane3(int& a, int& b, int& c, int va, int vb, int vc, int lane)
+__device__ __forceinline__ void writelane2(int& a, int& b, int va, int vb, int lane)
 {
-    asm("s_mov_b32 m0, %6\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\t"
-        "v_writelane_b32 %2, %5, m0"
-        : "+v"(a), "+v"(b), "+v"(c) : "s"(va), "s"(vb), "s"(vc), "s"(lane) : "m0");
+    asm("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+        : "+v"(a), "+v"(b) : "s"(va), "s"(vb), "s"(lane) : "m0");
 }
 __device__ __forceinline__ void writelane5(int& a, int& b, int& c, int& d, int& e, int va, int vb, int vc, int vd, int ve,
                                            int lane)
@@ -110,6 +109,7 @@ __device__ __noinline__ void exact_select_q64(const unsigned char* smem, const d
     out->idx = idx; out->gamma = gamma; out->c = c; out->cprev = cprev;
 }
 
+template <bool COMPACT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Q64_WAVES_PER_SIMD, Q64_WAVES_PER_SIMD)))
 void hop_q64_kernel(HopParams p)
 {
@@ -136,12 +136,19 @@ void hop_q64_kernel(HopParams p)
     uint64_t cb = 0;                       // lane j owns column j's bitmap
     for (int i = 0; i < 64; ++i) cb |= (uint64_t)(occ_g[i * 64 + lane] & 1u) << i;
     // column c lives at dword 3 * (c + 2); columns 0, 1 are mirrored at 64, 65 and 62, 63 at -2, -1
-    const int col_dw = 3 * (lane + 2);
-    const int col_mirror_dw = lane < 2 ? 3 * (lane + 66) : (lane >= 62 ? 3 * (lane - 62) : -1);
+    const bool col_mirrored = lane < 2 || lane >= 62;
     auto write_col = [&]() {
         const uint32_t lo = (uint32_t)cb, hi = (uint32_t)(cb >> 32);
+        // the addresses are recomputed from the lane number on every call (one multiply-add): hoisted
+        // out of the hop loop they are spilled to scratch memory at the 128-register limit
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int col_dw = 3 * (ln + 2);
         colw[col_dw] = lo; colw[col_dw + 1] = hi; colw[col_dw + 2] = lo;
-        if (col_mirror_dw >= 0) { colw[col_mirror_dw] = lo; colw[col_mirror_dw + 1] = hi; colw[col_mirror_dw + 2] = lo; }
+        if (col_mirrored) {
+            const int md = 3 * ((ln + 66) & 127);            // halo columns 66, 67 (lanes 0, 1) and 0, 1 (lanes 62, 63)
+            colw[md] = lo; colw[md + 1] = hi; colw[md + 2] = lo;
+        }
     };
     write_col();
     for (int s = lane; s < 256; s += KMC_WAVE) khp[s] = 0u;
@@ -178,13 +185,29 @@ void hop_q64_kernel(HopParams p)
     const long long hop0 = p.hops_done[r];
 
     // displacement tags: see kmc_hop_lds64.h (moved once per 64-hop chunk)
-    int tg_site = -1, tg_ow = 0, tg_vac = -1;
+    // here tg_site and tg_vac share one register: site | vac << 16 (registers are the scarce resource at 4 waves per SIMD)
+    int tg_sv = -1, tg_ow = 0;
     unsigned long long tg_live = 0ull, tg_root = 0ull;
 
     // entry pick: lane = 3 * (site in quarter) + m, entries 2m and 2m+1 of that site; lanes >= 48 masked out
     const int ent_site = lane < 48 ? lane / 3 : 0;
     const int ent_m = lane < 48 ? lane - 3 * ent_site : 0;
-    const uint32_t ent_off = (uint32_t)ent_m * 16u;
+    const uint32_t ent_off = COMPACT ? (uint32_t)ent_m * (KMC_COMPACT2_ROWS * 16u) : (uint32_t)ent_m * 16u;
+    // compact index of this lane's direction pair: up to 3 runs of consecutive key bits, packed
+    uint32_t cf_st[3], cf_ln[3], cf_sh[3];
+    {
+        uint32_t m = compact2_mask(ent_m), o = 0;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const uint32_t st = m ? (uint32_t)__builtin_ctz(m) : 0u;
+            const uint32_t inv = ~(m >> st);
+            const uint32_t ln = m ? (inv ? (uint32_t)__builtin_ctz(inv) : 32u) : 0u;
+            cf_st[f] = st; cf_ln[f] = ln; cf_sh[f] = o;
+            o += ln;
+            m = ln >= 32u ? 0u : (m & ~(((1u << ln) - 1u) << st));
+        }
+    }
+    const unsigned char* __restrict__ tc2_b = reinterpret_cast<const unsigned char*>(p.tcompact2);
     const uint32_t ent_sh = (uint32_t)ent_site * 2u;
     // window geometry by mode: i_lo = i - 2 + ext * min(di, 0), n_i = ni0 + ext * |di| (same for j)
     const int wm_ext = p.window_mode == 1 ? 0 : -1;    // all-ones mask: the window extends along the hop
@@ -202,17 +225,26 @@ void hop_q64_kernel(HopParams p)
     for (long long h0 = 0; h0 < my_hops && status == 0; h0 += KMC_WAVE) {
         const int cnt = (int)((my_hops - h0) < KMC_WAVE ? (my_hops - h0) : KMC_WAVE);
         // ---- uniforms for the next 64 hops, one hop per lane --------------
-        double rho_v = 0.5, u_v = 1.0;
-        if (lane < cnt) {
-            if (p.draws) {
-                const double2 dv = reinterpret_cast<const double2*>(p.draws)[(size_t)r * p.n_hops + h0 + lane];
-                rho_v = dv.x; u_v = dv.y;
-            } else {
-                const unsigned long long hh = (unsigned long long)(hop0 + h0 + lane);
-                u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r; c.w = KMC_STREAM_HOP;
-                const u32x4 o = philox4x32_10(c, p.seed_lo, p.seed_hi);
-                rho_v = u53(o.x, o.y); u_v = u53_open0(o.z, o.w);
+        // (the clock's draw u is needed only at the flush and is produced again there: two registers
+        // fewer across the hop loop, which runs at the 128-register limit of 4 waves per SIMD)
+        auto draw_pair = [&](double& rho, double& u) {
+            rho = 0.5; u = 1.0;
+            if (lane < cnt) {
+                if (p.draws) {
+                    const double2 dv = reinterpret_cast<const double2*>(p.draws)[(size_t)r * p.n_hops + h0 + lane];
+                    rho = dv.x; u = dv.y;
+                } else {
+                    const unsigned long long hh = (unsigned long long)(hop0 + h0 + lane);
+                    u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r; c.w = KMC_STREAM_HOP;
+                    const u32x4 o = philox4x32_10(c, p.seed_lo, p.seed_hi);
+                    rho = u53(o.x, o.y); u = u53_open0(o.z, o.w);
+                }
             }
+        };
+        double rho_v;
+        {
+            double u_unused;
+            draw_pair(rho_v, u_unused);
         }
         // per-lane record of hop (h0 + lane): gamma, chosen rate (as dwords, written with v_writelane), index
         int gam_lo = __double2loint(1.0), gam_hi = __double2hiint(1.0), pn_lo = gam_lo, pn_hi = gam_hi;
@@ -243,7 +275,15 @@ void hop_q64_kernel(HopParams p)
             // ---- entry: 16 sites x 6 directions, two entries per lane on 48 lanes ----------
             const uint32_t ek = (uint32_t)klo[i * 64 + q * 16 + ent_site] |
                                 (__builtin_amdgcn_ubfe(khp[i * 4 + q], ent_sh, 2u) << 16);
-            const double2 rr = *reinterpret_cast<const double2*>(table_b + (ek * 48u + ent_off));
+            double2 rr;
+            if (COMPACT) {
+                uint32_t ci = __builtin_amdgcn_ubfe(ek, cf_st[0], cf_ln[0]);
+#pragma unroll
+                for (int f = 1; f < 3; ++f) ci |= __builtin_amdgcn_ubfe(ek, cf_st[f], cf_ln[f]) << cf_sh[f];
+                rr = *reinterpret_cast<const double2*>(tc2_b + ((ci << 4) + ent_off));
+            } else {
+                rr = *reinterpret_cast<const double2*>(table_b + (ek * 48u + ent_off));
+            }
             const double esc = wave_scan_incl_z(rr.x + rr.y, sz);
             const double ap = qbase + esc;
             const double ape = qbase + dpp_f64<0x138, 0xF>(esc);
@@ -391,7 +431,7 @@ void hop_q64_kernel(HopParams p)
             ++hops;
             // tag move (:521-528): registers only, memory is touched at the chunk flush
             if (!presim) {
-                const unsigned long long m = ballot64(tg_site == s_src) & tg_live;
+                const unsigned long long m = ballot64((tg_sv & 0xFFFF) == s_src) & tg_live;
                 // tg_ow = origin lane | (wi + 64) << 8 | (wj + 64) << 16; |w| <= 64 inside a chunk
                 int ow = hl | (64 << 8) | (64 << 16);
                 if (m) {
@@ -402,7 +442,7 @@ void hop_q64_kernel(HopParams p)
                     tg_root |= 1ull << hl;                       // its tag is still in memory, at s_src
                 }
                 ow += ((ie >> 6) << 8) + ((je >> 6) << 16);      // wrap: floor(ie / 64) = -1, 0, +1
-                writelane3(tg_site, tg_ow, tg_vac, s_dst, ow, s_src, hl);
+                writelane2(tg_sv, tg_ow, s_dst | (s_src << 16), ow, hl);
                 tg_live |= 1ull << hl;
             }
             const double sumA = group8_sum(wA0 + wA1);
@@ -445,6 +485,7 @@ void hop_q64_kernel(HopParams p)
         const int done = hl;                // hops of this chunk that executed
         hist_v += (long long)((hist_s >> (8 * (lane & 7))) & 255ull); hist_s = 0ull;
         if (!presim && tg_root) {
+            const int tg_site = tg_sv & 0xFFFF, tg_vac = (int)((unsigned)tg_sv >> 16);
             // ---- move the chunk's tags: memory still holds the state before the chunk --------
             int4 tg_val = make_int4(0, 0, 0, 0);
             if ((tg_root >> lane) & 1ull) tg_val = tags_g[tg_vac];
@@ -465,10 +506,12 @@ void hop_q64_kernel(HopParams p)
             tv.w = __builtin_amdgcn_ds_bpermute(src, tg_val.w) + (((tg_ow >> 16) & 255) - 64);
             if (is_live) tags_g[tg_site] = tv;
             if ((vac >> lane) & 1ull) tags_g[tg_vac] = make_int4(-1, 0, 0, 0);
-            tg_live = 0ull; tg_root = 0ull; tg_site = -1;
+            tg_live = 0ull; tg_root = 0ull;        // stale tg_sv entries are masked by tg_live
         }
         const double gam_v = __hiloint2double(gam_hi, gam_lo), pn_v = __hiloint2double(pn_hi, pn_lo);
         if (!presim) {
+            double rho_unused, u_v;
+            draw_pair(rho_unused, u_v);
             const double dt = lane < done ? (-1.0 / gam_v) * log(u_v) : 0.0;      // :530
             time_acc += wave_sum(dt);
         }
