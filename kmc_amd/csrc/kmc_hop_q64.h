@@ -30,7 +30,9 @@ namespace kmc {
 #define Q64_KLO 0
 #define Q64_KHP 8192              // u32[256]: row r = dwords 4r .. 4r+3, site column c = bits 2(c&15) of dword c>>4
 #define Q64_COL 9216              // 12 B x 68: {lo, hi, lo} for columns -2 .. 65
-#define Q64_LDS_BYTES (Q64_COL + 68 * 12)
+#define Q64_MISC (Q64_COL + 68 * 12)   // i64 hist[6], f64 time, f64 barrier stats[5]: touched at the chunk flush only,
+                                      // kept here rather than in registers that would be spilled around the hop loop
+#define Q64_LDS_BYTES (Q64_MISC + 96)
 #define Q64_XSCRATCH 512          // bytes of global scratch per replica (exact path: 8 frames + the pick)
 #define Q64_WAVES_PER_SIMD 4
 
@@ -178,10 +180,12 @@ void hop_q64_kernel(HopParams p)
     int status = 0;
     long long n_exact = 0, hops = 0;
     unsigned long long hist_s = 0ull;      // 6 x 8-bit direction counters of the current chunk (scalar registers)
-    long long hist_v = 0;                  // lane d < 6 counts direction d
-    double time_acc = 0.0;
-    // barrier statistics: lane 0 = last, 1 = sum, 2 = min, 3 = max, 4 = count (one register pair)
-    double b_stat = lane == 0 ? p.barrier[r * 5 + 0] : (lane == 2 ? 1e300 : (lane == 3 ? -1e300 : 0.0));
+    long long* hist_l = reinterpret_cast<long long*>(smem + Q64_MISC);            // [6]
+    double* time_l = reinterpret_cast<double*>(smem + Q64_MISC + 48);              // launch clock
+    double* bstat_l = reinterpret_cast<double*>(smem + Q64_MISC + 56);             // last, sum, min, max, count
+    if (lane < 6) hist_l[lane] = 0;
+    if (lane == 0) time_l[0] = 0.0;
+    if (lane < 5) bstat_l[lane] = lane == 0 ? p.barrier[r * 5 + 0] : (lane == 2 ? 1e300 : (lane == 3 ? -1e300 : 0.0));
     const long long hop0 = p.hops_done[r];
 
     // displacement tags: see kmc_hop_lds64.h (moved once per 64-hop chunk)
@@ -483,7 +487,8 @@ void hop_q64_kernel(HopParams p)
         }
         // ---- flush the chunk: clock, trace, barrier diagnostics ----------------------
         const int done = hl;                // hops of this chunk that executed
-        hist_v += (long long)((hist_s >> (8 * (lane & 7))) & 255ull); hist_s = 0ull;
+        if (lane < 6) hist_l[lane] += (long long)((hist_s >> (8 * lane)) & 255ull);
+        hist_s = 0ull;
         if (!presim && tg_root) {
             const int tg_site = tg_sv & 0xFFFF, tg_vac = (int)((unsigned)tg_sv >> 16);
             // ---- move the chunk's tags: memory still holds the state before the chunk --------
@@ -513,7 +518,8 @@ void hop_q64_kernel(HopParams p)
             double rho_unused, u_v;
             draw_pair(rho_unused, u_v);
             const double dt = lane < done ? (-1.0 / gam_v) * log(u_v) : 0.0;      // :530
-            time_acc += wave_sum(dt);
+            const double tsum = wave_sum(dt);
+            if (lane == 0) time_l[0] += tsum;
         }
         if (p.sel && lane < cnt) p.sel[(size_t)r * p.n_hops + h0 + lane] = lane < done ? (idx_v & 0x3FFFFFFF) : -1;
         {
@@ -529,8 +535,11 @@ void hop_q64_kernel(HopParams p)
                     mn = fmin(mn, __shfl_xor(mn, off, 64));
                     mx = fmax(mx, __shfl_xor(mx, off, 64));
                 }
-                b_stat = lane == 0 ? last : (lane == 1 ? b_stat + sum : (lane == 2 ? fmin(b_stat, mn) :
-                         (lane == 3 ? fmax(b_stat, mx) : (lane == 4 ? b_stat + (double)__popcll(m) : b_stat))));
+                if (lane < 5) {
+                    const double b_stat = bstat_l[lane];
+                    bstat_l[lane] = lane == 0 ? last : (lane == 1 ? b_stat + sum : (lane == 2 ? fmin(b_stat, mn) :
+                                    (lane == 3 ? fmax(b_stat, mx) : b_stat + (double)__popcll(m))));
+                }
             }
         }
         if (status != 0 && p.sel) {
@@ -545,8 +554,10 @@ void hop_q64_kernel(HopParams p)
         // site s = (row s >> 6, column lane): its occupancy is a bit of this lane's own bitmap
         keys_g[s] = ((cb >> (s >> 6)) & 1ull) ? q64_key(klo, khp, s) : KMC_VACANT;
     }
-    if (lane < 6) p.hist[r * 6 + lane] += hist_v;
+    if (lane < 6) p.hist[r * 6 + lane] += hist_l[lane];
+    const double b_stat = lane < 5 ? bstat_l[lane] : 0.0;
     if (lane == 0) {
+        const double time_acc = time_l[0];
         p.time_total[r] += time_acc;
         p.step_time[r] = time_acc;
         p.gamma[r] = gamma;
