@@ -496,13 +496,11 @@ void hop_q64_kernel(HopParams p)
             if ((tg_root >> lane) & 1ull) tg_val = tags_g[tg_vac];
             const bool is_live = (tg_live >> lane) & 1ull;
             const int site_l = is_live ? tg_site : -1;
-            // a root's home site is vacant now unless a live atom sits on it
-            unsigned long long vac = 0ull;
-            for (unsigned long long rm = tg_root; rm; rm &= rm - 1ull) {
-                const int rl = __ffsll((long long)rm) - 1;
-                const int home = __builtin_amdgcn_readlane(tg_vac, rl);
-                if (ballot64(site_l == home) == 0ull) vac |= 1ull << rl;
-            }
+            // a root's home site is vacant now unless a live atom sits on it, i.e. unless the site is occupied:
+            // one read of the column bitmaps instead of a loop over the roots
+            const uint32_t hw = colw[3 * ((tg_vac & 63) + 2) + ((tg_vac >> 11) & 1)];
+            const bool home_empty = ((hw >> ((tg_vac >> 6) & 31)) & 1u) == 0u;
+            const unsigned long long vac = ballot64(home_empty) & tg_root;
             const int src = (tg_ow & 63) << 2;
             int4 tv;
             tv.x = __builtin_amdgcn_ds_bpermute(src, tg_val.x);
