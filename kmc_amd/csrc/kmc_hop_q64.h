@@ -37,6 +37,7 @@ namespace kmc {
 #define Q64_WAVES_PER_SIMD 4
 
 static_assert(Q64_LDS_BYTES <= 10240, "16 replicas per CU need <= 10 KB each");
+static_assert(Q64_KHP == 8192, "the ds_mskor_b32 in the hop loop carries this offset as an immediate");
 
 __device__ __forceinline__ uint32_t q64_key(const uint16_t* klo, const uint32_t* khp, int s)
 {
@@ -145,11 +146,13 @@ void hop_q64_kernel(HopParams p)
         // out of the hop loop they are spilled to scratch memory at the 128-register limit
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        const int col_dw = 3 * (ln + 2);
-        colw[col_dw] = lo; colw[col_dw + 1] = hi; colw[col_dw + 2] = lo;
+        typedef __attribute__((address_space(3))) uint32_t lds_u32;
+        lds_u32* cp = (lds_u32*)(uintptr_t)(lds_base + (uint32_t)Q64_COL + 12u * (uint32_t)(ln + 2));
+        cp[0] = lo; cp[1] = hi; cp[2] = lo;
         if (col_mirrored) {
-            const int md = 3 * ((ln + 66) & 127);            // halo columns 66, 67 (lanes 0, 1) and 0, 1 (lanes 62, 63)
-            colw[md] = lo; colw[md + 1] = hi; colw[md + 2] = lo;
+            // halo columns 66, 67 (lanes 0, 1) and 0, 1 (lanes 62, 63)
+            lds_u32* mp = (lds_u32*)(uintptr_t)(lds_base + (uint32_t)Q64_COL + 12u * (uint32_t)((ln + 66) & 127));
+            mp[0] = lo; mp[1] = hi; mp[2] = lo;
         }
     };
     write_col();
@@ -255,11 +258,23 @@ void hop_q64_kernel(HopParams p)
         int idx_v = -1;                    // bit 30 set: pn is already divided (exact path)
 
         int hl = 0;
+        int M_lo = 0, M_hi = 0, m_hi_limit = 0;      // margin in scalar registers; 0 limit: the first hop computes it
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the draws are in; nothing in the hop loop waits on them
         KMC_STAMP(0);
         for (; hl < cnt; ++hl) {
             const double t = readlane_f64(rho_v * gamma, hl);    // one multiply on all lanes: no scalar -> vector moves
-            const double M = gamma * mfac;
+            // margin: any M >= gamma * mfac certifies.  It is recomputed only when gamma has grown past the
+            // value it was computed from (scalar compare of the high words: gamma > 0), so most hops skip
+            // the multiply; it is never more than 2 * gamma * mfac... unless gamma shrank, which only makes
+            // the test more conservative (more exact-path hops, never a wrong pick) -- refreshed every chunk
+            if (__double2hiint(gamma) >= m_hi_limit) {
+                asm volatile("");
+                const double m2 = (2.0 * gamma) * mfac;
+                M_lo = __builtin_amdgcn_readfirstlane(__double2loint(m2));
+                M_hi = __builtin_amdgcn_readfirstlane(__double2hiint(m2));
+                m_hi_limit = __double2hiint(gamma) + 0x00100000;   // next binade: gamma < 2 * (gamma at refresh)
+            }
+            const double M = __hiloint2double(M_hi, M_lo);
             // ---- row ------------------------------------------------------
             const unsigned long long mr = ballot64(rowpre >= t);
             const int i = (__ffsll((long long)mr) - 1) & 63;
@@ -298,7 +313,8 @@ void hop_q64_kernel(HopParams p)
             const int el = (__ffsll((long long)me) - 1) & 63;
             // which of lane el's two entries: uniform, so a branch instead of six selects.  Only bit el
             // of the certification and lane el's rate are used
-            const bool fst = ((mfirst >> el) & 1ull) != 0ull;
+            const int snd = (int)((mfirst >> el) & 1ull) ^ 1;        // 0: lane el's first entry, 1: its second (scalar)
+            const bool fst = snd == 0;
             unsigned long long mok;
             int pnum_lo, pnum_hi;          // the chosen rate as two scalar dwords (v_writelane takes scalar sources only)
             if (fst) {
@@ -318,7 +334,7 @@ void hop_q64_kernel(HopParams p)
             {
                 const int es = el / 3;
                 j = q * 16 + es;
-                d = 2 * (el - 3 * es) + (fst ? 0 : 1);
+                d = 2 * (el - 3 * es) + snd;
             }
             if (!ok) {
                 // ---- exact sequential path (rare) --------------------------------
@@ -403,9 +419,9 @@ void hop_q64_kernel(HopParams p)
                 const int s = si * 64 + sj;
                 klo[s] = (uint16_t)knew;
                 const uint32_t fsh = (uint32_t)(sj & 15) * 2u;
-                const uint32_t haddr = lds_base + (uint32_t)(Q64_KHP + (s >> 4) * 4);
+                const uint32_t haddr = lds_base + (uint32_t)((s >> 4) * 4);
                 // MEM = (MEM & ~mask) | value: two key bits of one site inside the quarter's dword
-                asm volatile("ds_mskor_b32 %0, %1, %2" :: "v"(haddr), "v"(3u << fsh), "v"((knew >> 16) << fsh) : "memory");
+                asm volatile("ds_mskor_b32 %0, %1, %2 offset:8192" :: "v"(haddr), "v"(3u << fsh), "v"((knew >> 16) << fsh) : "memory");
             }
             KMC_STAMP(3);
             // ---- re-sum the touched quarters (8 lanes per half quarter) and rows -------------
@@ -421,7 +437,9 @@ void hop_q64_kernel(HopParams p)
                 const uint32_t hwA = khp[si * 4 + qa];
                 wA0 = load_w((uint32_t)klo[sA] | (__builtin_amdgcn_ubfe(hwA, 2u * grp_c, 2u) << 16));
                 wA1 = load_w((uint32_t)klo[sA + 8] | (__builtin_amdgcn_ubfe(hwA, 2u * grp_c + 16u, 2u) << 16));
-                if (two) {
+            }
+            if (two) {
+                if (act) {
                     const int sB = si * 64 + qb * 16 + grp_c;
                     const uint32_t hwB = khp[si * 4 + qb];
                     wB0 = load_w((uint32_t)klo[sB] | (__builtin_amdgcn_ubfe(hwB, 2u * grp_c, 2u) << 16));
