@@ -1,5 +1,7 @@
 // kmc_exact_par.h -- the reference's selection, hex_LiCoO2_kmc.py:486-492, replayed EXACTLY by a
-// whole 256-thread workgroup (the rare path of the large-lattice kernels, where 6n is millions).
+// whole workgroup: 256 threads in the large-lattice kernels, where 6n is millions, and the single
+// wave of hop_q64_kernel, where a literal one-lane replay of 24 576 entries would hold the launch
+// up for milliseconds (template parameter NW = waves; KeyFn(s) returns site s's key).
 //
 //     gamma = np.sum(P);  c_k = fl(c_{k-1} + P[k]);  idx = first k with fl(c_k / gamma) >= rho
 //
@@ -25,10 +27,7 @@
 
 namespace kmc {
 
-#define KMC_XP_THREADS 256
-#define KMC_XP_WAVES 4
-#define KMC_XP_SITES 4                       // sites per thread and tile
-#define KMC_XP_TILE (KMC_XP_THREADS * KMC_XP_SITES * 6)
+#define KMC_XP_WAVES 4                       // at most
 #define KMC_XP_NOEV 0xFFFFFFFFFFFFFFFFull
 
 struct ExactParShared {
@@ -61,13 +60,13 @@ __device__ __forceinline__ uint32_t xp_row(uint32_t k) { return k > 0x3FFFFu ? 0
 // numpy's 128-element leaf (8 interleaved accumulators) over entries [lo, lo + 128) of the flattened
 // rate matrix, lo % 6 == O.  Everything is unrolled with compile-time positions so that the 22 rows
 // the leaf covers are loaded as independent 16-byte loads and stay in registers.
-template <int O>
-__device__ __forceinline__ double xp_leaf128(const uint32_t* __restrict__ keys, const double* __restrict__ table, long lo)
+template <int O, class KeyFn>
+__device__ __forceinline__ double xp_leaf128(KeyFn keys, const double* __restrict__ table, long lo)
 {
     const long s0 = (lo - O) / 6;
     uint32_t k[22];
 #pragma unroll
-    for (int q = 0; q < 22; ++q) k[q] = xp_row(keys[s0 + q]);          // 22 loads in flight
+    for (int q = 0; q < 22; ++q) k[q] = xp_row(keys(s0 + q));          // 22 loads in flight
     double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool first[8] = {true, true, true, true, true, true, true, true};
 #pragma unroll
@@ -99,6 +98,26 @@ __device__ __forceinline__ double xp_leaf128(const uint32_t* __restrict__ keys, 
     return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
 }
 
+// The same leaf with run-time loops and 8 loads in flight: ~40 registers instead of ~170, for callers
+// that must stay inside a small register budget (hop_q64_kernel: 128).
+template <class KeyFn>
+__device__ __forceinline__ double xp_leaf128_lean(KeyFn keys, const double* __restrict__ table, long lo)
+{
+    auto entry = [&](long e) -> double {
+        const long s = e / 6;
+        return table[(size_t)xp_row(keys(s)) * 6 + (int)(e - 6 * s)];
+    };
+    double r0 = entry(lo), r1 = entry(lo + 1), r2 = entry(lo + 2), r3 = entry(lo + 3),
+           r4 = entry(lo + 4), r5 = entry(lo + 5), r6 = entry(lo + 6), r7 = entry(lo + 7);
+#pragma unroll 1
+    for (long i = lo + 8; i < lo + 128; i += 8) {
+        const double a0 = entry(i), a1 = entry(i + 1), a2 = entry(i + 2), a3 = entry(i + 3),
+                     a4 = entry(i + 4), a5 = entry(i + 5), a6 = entry(i + 6), a7 = entry(i + 7);
+        r0 += a0; r1 += a1; r2 += a2; r3 += a3; r4 += a4; r5 += a5; r6 += a6; r7 += a7;
+    }
+    return ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+}
+
 // inclusive prefix sum of a 64-bit integer over the wave (DPP, same steps as wave_scan_incl)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ long long dpp_i64(long long x)
@@ -122,9 +141,12 @@ __device__ __forceinline__ long long wave_scan_incl_i64(long long x)
 // Result in sh->idx, sh->gamma, sh->c_found, sh->cprev_found (every thread may read them after the
 // call; the call ends with a barrier).  keys: KMC_VACANT = vacant; table must have the all-zero row
 // 0x7FFFF (kmc_create allocates 2^19 rows for that).
-__device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys, const double* __restrict__ table,
-                                              int n, double rho, ExactParShared* sh)
+template <int NW, int KMC_XP_SITES, bool LEAN, class KeyFn>     // KMC_XP_SITES = sites per thread and tile
+__device__ __forceinline__ void exact_select_par_impl(KeyFn keys, const double* __restrict__ table,
+                                                      int n, double rho, ExactParShared* sh)
 {
+    constexpr int XP_THREADS = 64 * NW;
+    constexpr long XP_TILE = (long)XP_THREADS * KMC_XP_SITES * 6;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef KMC_XP_TRACE
     const unsigned long long xp_t0 = __builtin_amdgcn_s_memtime();
@@ -132,18 +154,20 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
     auto entry = [&](long e) -> double {
         const int s = (int)(e / 6);
         const int d = (int)(e - 6 * (long)s);
-        return table[(size_t)xp_row(keys[s]) * 6 + d];
+        return table[(size_t)xp_row(keys(s)) * 6 + d];
     };
     // ---- np.sum: full 8192-element buffers, one wave each (lane = 128-element leaf)
     const long n6 = 6L * n;
     const long nfull = n6 / 8192;
     double total = 0.0;                                   // meaningful in thread 0
-    for (long c0 = 0; c0 < nfull; c0 += KMC_XP_WAVES) {
+    for (long c0 = 0; c0 < nfull; c0 += NW) {
         const long c = c0 + wv;
         if (c < nfull) {
             const long lo = c * 8192 + (long)lane * 128;
             const int o = (int)(lo % 6);                  // 0, 2 or 4: 8192 and 128 are both 2 (mod 6)
-            double res = o == 0 ? xp_leaf128<0>(keys, table, lo) : (o == 2 ? xp_leaf128<2>(keys, table, lo) : xp_leaf128<4>(keys, table, lo));
+            double res;
+            if (LEAN) res = xp_leaf128_lean(keys, table, lo);
+            else res = o == 0 ? xp_leaf128<0>(keys, table, lo) : (o == 2 ? xp_leaf128<2>(keys, table, lo) : xp_leaf128<4>(keys, table, lo));
             // pairwise tree over the 64 leaves: lower half + upper half at every level
             for (int b = 1; b < 64; b <<= 1) {
                 const double other = __shfl_xor(res, b, 64);
@@ -153,7 +177,7 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
         }
         __syncthreads();
         if (tid == 0)
-            for (int q = 0; q < KMC_XP_WAVES && c0 + q < nfull; ++q) total = total + sh->chunk_sum[q];
+            for (int q = 0; q < NW && c0 + q < nfull; ++q) total = total + sh->chunk_sum[q];
         __syncthreads();
     }
     if (tid == 0) {
@@ -189,7 +213,7 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
 #pragma unroll
     for (int q = 0; q < KMC_XP_SITES; ++q) {
         const long s = (long)tid * KMC_XP_SITES + q;
-        knext[q] = s < n ? keys[s] : KMC_VACANT;
+        knext[q] = s < n ? keys(s) : KMC_VACANT;
     }
     // The running state (c, pos) is uniform and lives in registers: every thread derives it from the
     // same shared totals.  An event-free tile costs one barrier (wave totals are double-buffered).
@@ -198,8 +222,8 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
     int parity = 0;
     bool done = false;
     const int NE = KMC_XP_SITES * 6;
-    for (long tile0 = 0; tile0 < n6 && !done; tile0 += KMC_XP_TILE) {
-        const long tile_end = (tile0 + KMC_XP_TILE) < n6 ? (tile0 + KMC_XP_TILE) : n6;
+    for (long tile0 = 0; tile0 < n6 && !done; tile0 += XP_TILE) {
+        const long tile_end = (tile0 + XP_TILE) < n6 ? (tile0 + XP_TILE) : n6;
         const long e0 = tile0 + (long)tid * NE;
         double p[KMC_XP_SITES * 6];
 #pragma unroll
@@ -213,8 +237,8 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
         }
 #pragma unroll
         for (int q = 0; q < KMC_XP_SITES; ++q) {          // the next tile's keys travel while this one is summed
-            const long s = (e0 + KMC_XP_TILE) / 6 + q;
-            knext[q] = s < n ? keys[s] : KMC_VACANT;
+            const long s = (e0 + XP_TILE) / 6 + q;
+            knext[q] = s < n ? keys(s) : KMC_VACANT;
         }
         const long hi_l = tile_end - e0;
         const int hi_m = hi_l < 0 ? 0 : (hi_l > NE ? NE : (int)hi_l);      // my entries [lo_m, hi_m) are live
@@ -259,7 +283,7 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
             long long base = A + (incl - run), tot = 0;
             int anyflag = 0;
 #pragma unroll
-            for (int q = 0; q < KMC_XP_WAVES; ++q) {
+            for (int q = 0; q < NW; ++q) {
                 const long long wt = sh->wave_tot[parity][q];
                 if (q < wv) base += wt;
                 tot += wt;
@@ -322,6 +346,13 @@ __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys,
     }
     __syncthreads();
     XP_TRACE(6, __builtin_amdgcn_s_memtime() - xp_t0);
+}
+
+// the 256-thread instance of the large-lattice kernels; keys in global memory, KMC_VACANT = vacant
+__device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys, const double* __restrict__ table,
+                                              int n, double rho, ExactParShared* sh)
+{
+    exact_select_par_impl<4, 4, false>([&](long s) -> uint32_t { return keys[s]; }, table, n, rho, sh);
 }
 
 }  // namespace kmc

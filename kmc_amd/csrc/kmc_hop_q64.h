@@ -23,6 +23,7 @@
 #include "kmc_device.h"
 #include "kmc_hop_lds.h"
 #include "kmc_hop_lds64.h"
+#include "kmc_exact_par.h"
 
 namespace kmc {
 
@@ -33,7 +34,7 @@ namespace kmc {
 #define Q64_MISC (Q64_COL + 68 * 12)   // i64 hist[6], f64 time, f64 barrier stats[5]: touched at the chunk flush only,
                                       // kept here rather than in registers that would be spilled around the hop loop
 #define Q64_LDS_BYTES (Q64_MISC + 96)
-#define Q64_XSCRATCH 512          // bytes of global scratch per replica (exact path: 8 frames + the pick)
+#define Q64_XSCRATCH 1024         // bytes of global scratch per replica (exact path: ExactParShared)
 #define Q64_WAVES_PER_SIMD 4
 
 static_assert(Q64_LDS_BYTES <= 10240, "16 replicas per CU need <= 10 KB each");
@@ -79,37 +80,22 @@ __device__ __forceinline__ double wave_scan_incl_z(double x, ScanZero& z)
     return x;
 }
 
-// literal restatement of hex_LiCoO2_kmc.py:486-492, see exact_select() in kmc_hop_lds.h
-__device__ __noinline__ void exact_select_q64(const unsigned char* smem, const double* table, double rho,
-                                              PwFrame* frames, ExactPick* out)
+static_assert(sizeof(ExactParShared) <= Q64_XSCRATCH, "exact-path scratch");
+
+// The reference's selection replayed exactly (hex_LiCoO2_kmc.py:486-492) by the replica's one wave:
+// kmc_exact_par.h with the keys read from the packed LDS planes.  ~50 us instead of the ~2.5 ms a
+// one-lane replay of the 24 576 entries takes -- which matters although only one hop in ~1e8 comes here:
+// a launch of 8.4e6 hops ends when its slowest replica does.  The lean instance (2 sites per lane and
+// tile, looped leaves) keeps the function inside the kernel's 128-register budget: a callee's registers
+// count towards the kernel's.
+// (Built with -mllvm -enable-ipra=0, kmc_amd/build.py: with inter-procedural register allocation the
+// kernel sees this function clobber ~100 scalar registers and spills its own all over the hop loop;
+// under the plain calling convention the callee saves what it uses.  Inlined it is worse still.)
+__device__ __noinline__ void exact_select_q64(const unsigned char* smem, const double* table, double rho, ExactParShared* sh)
 {
     const uint16_t* klo = reinterpret_cast<const uint16_t*>(smem + Q64_KLO);
     const uint32_t* khp = reinterpret_cast<const uint32_t*>(smem + Q64_KHP);
-    auto entry = [&](long e) -> double {
-        const int s = (int)(e / 6);
-        const int d = (int)(e - 6 * (long)s);
-        return table[(size_t)q64_key(klo, khp, s) * 6 + d];
-    };
-    const long n6 = 6L * 4096;
-    const double gamma = np_sum_model(n6, entry, frames);
-    double c = 0., cprev = 0.;
-    long idx = n6;
-    if (0.0 / gamma >= rho) {
-        idx = 0;
-    } else {
-        for (int s = 0; s < 4096 && idx == n6; ++s) {
-            const uint32_t k = q64_key(klo, khp, s);
-            if (k == Q64_VAC) continue;            // a zero row: + 0.0 changes nothing
-            for (int d = 0; d < 6; ++d) {
-                const double pv = table[(size_t)k * 6 + d];
-                if (pv == 0.0) continue;
-                cprev = c;
-                c += pv;
-                if (c / gamma >= rho) { idx = (long)s * 6 + d; break; }
-            }
-        }
-    }
-    out->idx = idx; out->gamma = gamma; out->c = c; out->cprev = cprev;
+    exact_select_par_impl<1, 2, true>([=](long s) -> uint32_t { return q64_key(klo, khp, (int)s); }, table, 4096, rho, sh);
 }
 
 template <bool COMPACT>
@@ -122,8 +108,7 @@ void hop_q64_kernel(HopParams p)
     uint16_t* klo = reinterpret_cast<uint16_t*>(smem + Q64_KLO);
     uint32_t* khp = reinterpret_cast<uint32_t*>(smem + Q64_KHP);
     uint32_t* colw = reinterpret_cast<uint32_t*>(smem + Q64_COL);
-    PwFrame* frames = reinterpret_cast<PwFrame*>(reinterpret_cast<unsigned char*>(p.xscratch) + (size_t)r * Q64_XSCRATCH);
-    ExactPick* pick = reinterpret_cast<ExactPick*>(frames + K64_NFRAMES);
+    ExactParShared* xsh = reinterpret_cast<ExactParShared*>(reinterpret_cast<unsigned char*>(p.xscratch) + (size_t)r * Q64_XSCRATCH);
 
     uint8_t* occ_g = p.occ + (size_t)r * 4096;
     uint32_t* keys_g = p.keys + (size_t)r * 4096;
@@ -229,7 +214,14 @@ void hop_q64_kernel(HopParams p)
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
-    for (long long h0 = 0; h0 < my_hops && status == 0; h0 += KMC_WAVE) {
+    // Hops run in chunks of up to 64 (one hop's draws per lane).  A hop that cannot be certified ENDS its
+    // chunk early: the chunk is flushed with the hops done so far and the next chunk starts with that hop,
+    // whose exact selection is computed first (need_exact).  The exact path is a function call, and a call
+    // anywhere inside the hop loop's nest makes the compiler spill scalar registers all over the loop
+    // (+75 vector instructions per hop); up here hardly anything is live.
+    bool need_exact = false;
+    int done = 0;
+    for (long long h0 = 0; h0 < my_hops && status == 0; h0 += done) {
         const int cnt = (int)((my_hops - h0) < KMC_WAVE ? (my_hops - h0) : KMC_WAVE);
         // ---- uniforms for the next 64 hops, one hop per lane --------------
         // (the clock's draw u is needed only at the flush and is produced again there: two registers
@@ -259,9 +251,22 @@ void hop_q64_kernel(HopParams p)
 
         int hl = 0;
         int M_lo = 0, M_hi = 0, m_hi_limit = 0;      // margin in scalar registers; 0 limit: the first hop computes it
+        bool ex_have = false;                   // hop 0 of the chunk takes the exact answer waiting in xsh
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the draws are in; nothing in the hop loop waits on them
+        int run = cnt;                          // hops this chunk may run (0 if the exact path stops the replica)
+        if (need_exact) {
+            // ---- exact path (rare): the reference's selection replayed literally for hop h0 -----
+            need_exact = false;
+            wave_fence();
+            exact_select_q64(smem, p.table, readlane_f64(rho_v, 0), xsh);
+            wave_fence();
+            ++n_exact;
+            if (!(xsh->gamma > 0.0)) { status = 2; run = 0; }
+            else if (xsh->idx >= 6L * 4096) { status = 1; run = 0; }
+            else ex_have = true;
+        }
         KMC_STAMP(0);
-        for (; hl < cnt; ++hl) {
+        for (; hl < run; ++hl) {
             const double t = readlane_f64(rho_v * gamma, hl);    // one multiply on all lanes: no scalar -> vector moves
             // margin: any M >= gamma * mfac certifies.  It is recomputed only when gamma has grown past the
             // value it was computed from (scalar compare of the high words: gamma > 0), so most hops skip
@@ -336,20 +341,16 @@ void hop_q64_kernel(HopParams p)
                 j = q * 16 + es;
                 d = 2 * (el - 3 * es) + snd;
             }
-            if (!ok) {
-                // ---- exact sequential path (rare) --------------------------------
-                wave_fence();
-                exact_select_q64(smem, p.table, readlane_f64(rho_v, hl), frames, pick);
-                wave_fence();
-                ++n_exact;
-                const long idx = pick->idx;
-                const double g = pick->gamma;
-                if (!(g > 0.0)) { status = 2; break; }
-                if (idx >= 6L * 4096) { status = 1; break; }
-                d = (int)(idx % 6);
-                j = (int)((idx / 6) & 63);
-                i_sel = (int)((idx / 6) >> 6);
-                const double pn = pick->c / g - pick->cprev / g;      // the reference's own expression (:497)
+            if (!ok && !ex_have) { need_exact = true; break; }      // the chunk ends here
+            if (ex_have) {
+                asm volatile("");
+                ex_have = false;
+                const long ex_idx = xsh->idx;
+                const double g = xsh->gamma;
+                const double pn = xsh->c_found / g - xsh->cprev_found / g;      // the reference's own expression (:497)
+                d = (int)(ex_idx % 6);
+                j = (int)((ex_idx / 6) & 63);
+                i_sel = (int)((ex_idx / 6) >> 6);
                 pnum_lo = __builtin_amdgcn_readfirstlane(__double2loint(pn));
                 pnum_hi = __builtin_amdgcn_readfirstlane(__double2hiint(pn));
                 exact_flag = 1 << 30;
@@ -504,7 +505,7 @@ void hop_q64_kernel(HopParams p)
             KMC_STAMP(5);
         }
         // ---- flush the chunk: clock, trace, barrier diagnostics ----------------------
-        const int done = hl;                // hops of this chunk that executed
+        done = hl;                          // hops of this chunk that executed
         if (lane < 6) hist_l[lane] += (long long)((hist_s >> (8 * lane)) & 255ull);
         hist_s = 0ull;
         if (!presim && tg_root) {
@@ -537,7 +538,8 @@ void hop_q64_kernel(HopParams p)
             const double tsum = wave_sum(dt);
             if (lane == 0) time_l[0] += tsum;
         }
-        if (p.sel && lane < cnt) p.sel[(size_t)r * p.n_hops + h0 + lane] = lane < done ? (idx_v & 0x3FFFFFFF) : -1;
+        // a stopped replica fills the rest of its trace with -1; otherwise later chunks write the hops not done here
+        if (p.sel && lane < (status != 0 ? cnt : done)) p.sel[(size_t)r * p.n_hops + h0 + lane] = lane < done ? (idx_v & 0x3FFFFFFF) : -1;
         {
             const bool has = lane < done && (idx_v & 0x3FFFFFFF) != 0;           // :495
             const double pd_v = (idx_v & (1 << 30)) ? 1.0 : gam_v;

@@ -20,7 +20,8 @@ for l in body.split('\n'):
     if mm: cur = mm.group(1)
     if cur not in blocks: blocks[cur] = []; order.append(cur)
     blocks[cur].append(l)
-depth2 = [b for b in order if any('Depth=2' in l for l in blocks[b][:3])]
+DEPTH = os.environ.get('DEPTH', '2')
+depth2 = [b for b in order if any('Depth=' + DEPTH in l for l in blocks[b][:3])]
 tot = {'valu': 0, 'salu': 0, 'lds': 0, 'vmem': 0, 'scratch': 0}
 text = []
 for b in depth2:
