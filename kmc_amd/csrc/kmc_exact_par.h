@@ -23,7 +23,6 @@
 // c* the smallest double that satisfies it (found once, by stepping ulps around rho * gamma).
 #pragma once
 #include "kmc_device.h"
-#include "kmc_hop_lds.h"
 
 namespace kmc {
 

@@ -35,6 +35,7 @@
 // Otherwise (about 3e-8 of hops at 64x64) exact_select() replays the reference.
 #pragma once
 #include "kmc_device.h"
+#include "kmc_exact_par.h"
 
 namespace kmc {
 
@@ -85,35 +86,12 @@ struct ExactPick { long idx; double gamma, c, cprev; };
 // Literal restatement of hex_LiCoO2_kmc.py:486-492 on the stale-key state:
 // gamma with np.sum's association, strictly sequential cumsum, first index whose
 // normalised value reaches rho.  Every lane runs it redundantly (uniform).
-__device__ __noinline__ void exact_select(const uint32_t* key, const double* table, int n, double rho,
-                                          PwFrame* frames, ExactPick* out)
+// The reference's selection replayed exactly by the replica's one wave (kmc_exact_par.h: np.sum's tree,
+// the sequential cumsum as binade-wise integer prefix sums).  A literal one-lane replay of the 6n entries
+// takes milliseconds at 64 x 64, and a launch ends when its slowest replica does.
+__device__ __noinline__ void exact_select(const uint32_t* key, const double* table, int n, double rho, ExactParShared* sh)
 {
-    auto entry = [&](long e) -> double {
-        const int s = (int)(e / 6);
-        const int d = (int)(e - 6 * (long)s);
-        const uint32_t k = key[s];
-        return k == KMC_VACANT ? 0.0 : table[(size_t)k * 6 + d];
-    };
-    const long n6 = 6L * n;
-    const double gamma = np_sum_model(n6, entry, frames);
-    double c = 0., cprev = 0.;
-    long idx = n6;
-    if (0.0 / gamma >= rho) {
-        idx = 0;                                   // searchsorted(left) with rho <= 0
-    } else {
-        for (int s = 0; s < n && idx == n6; ++s) {
-            const uint32_t k = key[s];
-            if (k == KMC_VACANT) continue;         // + 0.0 changes nothing
-            for (int d = 0; d < 6; ++d) {
-                const double pv = table[(size_t)k * 6 + d];
-                if (pv == 0.0) continue;
-                cprev = c;
-                c += pv;
-                if (c / gamma >= rho) { idx = (long)s * 6 + d; break; }
-            }
-        }
-    }
-    out->idx = idx; out->gamma = gamma; out->c = c; out->cprev = cprev;
+    exact_select_par_impl<1, 2, true>([=](long s) -> uint32_t { return key[s]; }, table, n, rho, sh);
 }
 
 #define KMC_LDS_FRAMES 16        // pairwise recursion depth for n6 <= 8192 per buffer is 7
@@ -123,14 +101,16 @@ __host__ __device__ inline size_t hop_lds_layout(int nx, int n, size_t* off_blk,
     size_t o = ((size_t)4 * n + 15) & ~(size_t)15;           // key
     *off_blk = o; o += (size_t)nx * 8 * 8;                   // blk
     *off_col = o; o += 64 * 8;                               // col
-    *off_frames = o; o += sizeof(PwFrame) * KMC_LDS_FRAMES + sizeof(ExactPick) + 16;
+    *off_frames = o; o += (sizeof(ExactParShared) + 15) & ~(size_t)15;
     return o;
 }
 
 #ifdef KMC_LDS_WAVES            // occupancy experiments only (scripts/probe_occupancy.py)
 #define KMC_LDS_ATTR __attribute__((amdgpu_waves_per_eu(KMC_LDS_WAVES, KMC_LDS_WAVES)))
 #else
-#define KMC_LDS_ATTR
+// at least 3 waves per SIMD (<= 168 registers): the budget also binds the exact path the kernel calls,
+// which would take 226 registers left alone; small lattices run 12 replicas per CU
+#define KMC_LDS_ATTR __attribute__((amdgpu_waves_per_eu(3)))
 #endif
 
 __global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
@@ -143,8 +123,7 @@ __global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
     uint32_t* key = reinterpret_cast<uint32_t*>(smem);
     double* blk = reinterpret_cast<double*>(smem + off_blk);
     uint64_t* col = reinterpret_cast<uint64_t*>(smem + off_col);
-    PwFrame* frames = reinterpret_cast<PwFrame*>(smem + off_frames);
-    ExactPick* pick = reinterpret_cast<ExactPick*>(frames + KMC_LDS_FRAMES);
+    ExactParShared* xsh = reinterpret_cast<ExactParShared*>(smem + off_frames);
 
     uint8_t* occ_g = p.occ + (size_t)r * n;
     uint32_t* keys_g = p.keys + (size_t)r * n;
@@ -268,17 +247,17 @@ __global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
             if (!ok) {
                 // ---- exact sequential path (rare) --------------------------------
                 wave_fence();
-                exact_select(key, p.table, n, rho, frames, pick);
+                exact_select(key, p.table, n, rho, xsh);
                 wave_fence();
                 ++n_exact;
-                const long idx = pick->idx;
-                const double g = pick->gamma;
+                const long idx = xsh->idx;
+                const double g = xsh->gamma;
                 if (!(g > 0.0)) { status = 2; break; }
                 if (idx >= 6L * n) { status = 1; break; }
                 d = (int)(idx % 6);
                 j = (int)((idx / 6) % ny);
                 i = (int)((idx / 6) / ny);
-                pnum = pick->c / g - pick->cprev / g;      // the reference's own expression (:497)
+                pnum = xsh->c_found / g - xsh->cprev_found / g;      // the reference's own expression (:497)
                 pden = 1.0;
             }
             KMC_STAMP(2);

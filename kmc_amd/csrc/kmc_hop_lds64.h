@@ -6,7 +6,7 @@
 // of which ~600 are memory waits (scripts/stamps.py), so every instruction on the chain
 // counts and the number of replicas resident per CU (LDS bytes) sets the throughput.
 //
-// LDS per replica, 17 760 B (9 replicas per CU would fit, 8 run: see K64_WAVES_PER_SIMD; the
+// LDS per replica, 18 496 B (8 replicas per CU, see K64_WAVES_PER_SIMD; the
 // generic layout allows 7):
 //   klo  u16[4096]   low 16 bits of each site's key at its last refresh
 //   khi  u8 [4096]   bits 16..18: bit 18 set = vacant.  A vacant site is key 0x7FFFF, whose rates
@@ -16,7 +16,7 @@
 //                    each side mirror the periodic wrap).  A read at +0 sees rows 0..63, a
 //                    read at +4 sees the bitmap rotated by 32 rows, so the 5 rows around any
 //                    site are ONE v_alignbit_b32 per column, wrap included
-//   frames, pick     exact path only
+//   xsh              exact path only (ExactParShared, 1 KB)
 //
 // Differences from the generic kernel that shorten the chain:
 //   * the six rates of a site come from the compact per-direction table Tc[6][2^13] (393 KB, L2
@@ -48,10 +48,8 @@ namespace kmc {
 #define K64_KHI 8192
 #define K64_BLK 12288
 #define K64_COL 16384
-#define K64_FRAMES (K64_COL + 68 * 16)
-#define K64_NFRAMES 8             // np.sum's pairwise recursion over 8192-element buffers is 7 deep
-#define K64_PICK (K64_FRAMES + K64_NFRAMES * 32)
-#define K64_LDS_BYTES (K64_PICK + 32)
+#define K64_XSH (K64_COL + 68 * 16)   // ExactParShared: the exact path's state
+#define K64_LDS_BYTES (K64_XSH + 1024)
 // Exactly two waves per SIMD (8 replicas per CU), enforced through the register allocation
 // (amdgpu_waves_per_eu): the kernel is latency bound, a round of replicas lasts as long as its
 // slowest wave, and a SIMD that is given a third wave slows all three.  Measured on 4096 replicas
@@ -59,43 +57,18 @@ namespace kmc {
 // CU to 9 workgroups, and 6.9 ms when LDS limits it to 8 but a SIMD may still take three.
 #define K64_WAVES_PER_SIMD 2
 
-static_assert(sizeof(PwFrame) == 32, "frame size");
-static_assert(sizeof(ExactPick) == 32, "pick size");
+static_assert(sizeof(ExactParShared) <= 1024, "exact-path state");
 
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-// literal restatement of hex_LiCoO2_kmc.py:486-492, see exact_select() in kmc_hop_lds.h
-__device__ __noinline__ void exact_select64(const unsigned char* smem, const double* table, double rho,
-                                            PwFrame* frames, ExactPick* out)
+// the reference's selection replayed exactly by the wave, see exact_select() in kmc_hop_lds.h
+__device__ __noinline__ void exact_select64(const unsigned char* smem, const double* table, double rho, ExactParShared* sh)
 {
     const uint16_t* klo = reinterpret_cast<const uint16_t*>(smem + K64_KLO);
     const uint8_t* khi = smem + K64_KHI;
-    auto entry = [&](long e) -> double {
-        const int s = (int)(e / 6);
-        const int d = (int)(e - 6 * (long)s);
-        const uint32_t k = (uint32_t)klo[s] | ((uint32_t)khi[s] << 16);
-        return table[(size_t)k * 6 + d];
-    };
-    const long n6 = 6L * 4096;
-    const double gamma = np_sum_model(n6, entry, frames);
-    double c = 0., cprev = 0.;
-    long idx = n6;
-    if (0.0 / gamma >= rho) {
-        idx = 0;
-    } else {
-        for (int s = 0; s < 4096 && idx == n6; ++s) {
-            const uint32_t k = (uint32_t)klo[s] | ((uint32_t)khi[s] << 16);
-            if (k == K64_VAC) continue;
-            for (int d = 0; d < 6; ++d) {
-                const double pv = table[(size_t)k * 6 + d];
-                if (pv == 0.0) continue;
-                cprev = c;
-                c += pv;
-                if (c / gamma >= rho) { idx = (long)s * 6 + d; break; }
-            }
-        }
-    }
-    out->idx = idx; out->gamma = gamma; out->c = c; out->cprev = cprev;
+    // a vacant site is 0x7FFFF here: xp_row() maps everything above 0x3FFFF to the zero row
+    exact_select_par_impl<1, 2, true>([=](long s) -> uint32_t { return (uint32_t)klo[s] | ((uint32_t)khi[s] << 16); },
+                                      table, 4096, rho, sh);
 }
 
 template <bool COMPACT>
@@ -109,8 +82,7 @@ void hop_lds64_kernel(HopParams p)
     uint8_t* khi = smem + K64_KHI;
     double* blk = reinterpret_cast<double*>(smem + K64_BLK);
     uint32_t* colw = reinterpret_cast<uint32_t*>(smem + K64_COL);
-    PwFrame* frames = reinterpret_cast<PwFrame*>(smem + K64_FRAMES);
-    ExactPick* pick = reinterpret_cast<ExactPick*>(smem + K64_PICK);
+    ExactParShared* xsh = reinterpret_cast<ExactParShared*>(smem + K64_XSH);
 
     uint8_t* occ_g = p.occ + (size_t)r * 4096;
     uint32_t* keys_g = p.keys + (size_t)r * 4096;
@@ -272,17 +244,17 @@ void hop_lds64_kernel(HopParams p)
             if (!ok) {
                 // ---- exact sequential path (rare) --------------------------------
                 wave_fence();
-                exact_select64(smem, p.table, readlane_f64(rho_v, hl), frames, pick);
+                exact_select64(smem, p.table, readlane_f64(rho_v, hl), xsh);
                 wave_fence();
                 ++n_exact;
-                const long idx = pick->idx;
-                const double g = pick->gamma;
+                const long idx = xsh->idx;
+                const double g = xsh->gamma;
                 if (!(g > 0.0)) { status = 2; break; }
                 if (idx >= 6L * 4096) { status = 1; break; }
                 d = (int)(idx % 6);
                 j = (int)((idx / 6) & 63);
                 i_sel = (int)((idx / 6) >> 6);
-                pnum = pick->c / g - pick->cprev / g;      // the reference's own expression (:497)
+                pnum = xsh->c_found / g - xsh->cprev_found / g;      // the reference's own expression (:497)
                 exact_flag = 1 << 30;
             }
             KMC_STAMP(2);
