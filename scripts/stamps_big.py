@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import kmc_amd
 from kmc_amd import _lib
-t = np.load('tests/golden/tables.npz')
+t = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests/golden/tables.npz'))
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 eng = kmc_amd.KMCEngine(1, nx)
