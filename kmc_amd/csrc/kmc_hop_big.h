@@ -247,7 +247,13 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
-    for (long long h = 0; wv == 0 && h < my_hops && status == 0; ++h) {
+    // The exact path is a function call; inside the hop loop it makes the compiler spill scalar registers
+    // throughout the loop.  A hop that is not certified leaves the loop, the call is made in the outer
+    // loop, and the hop loop is re-entered at the same hop with the answer waiting in xp (ex_have).
+    bool ex_have = false;
+    long long h = 0;
+    for (;;) {
+    for (; wv == 0 && h < my_hops && status == 0; ++h) {
         const int hl = (int)(h & 63);
         int i = 0, j = 0, d = 0;
         double pnum = 1.0;
@@ -337,22 +343,13 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             d = el - 6 * es;
         }
         KMC_STAMP(2);
-        const bool need_exact = !ok;
-        if (need_exact) {
-            // publish the keys this wave stored, wake the helpers, replay the reference together
-            __threadfence_block();
-            if (lane == 0) { *(volatile double*)&ctl->rho = rho; *(volatile int*)&ctl->seq = ++seq_sent; }
-            else ++seq_sent;
-            exact_select_par(keys_g, p.table, n, rho, xp);
-        }
-
+        if (!ok && !ex_have) break;                          // to the exact path in the outer loop
         int exact_flag = 0;
-        if (need_exact) {
-            ++n_exact;
+        if (ex_have) {
+            asm volatile("");
+            ex_have = false;
             const long long idx = xp->idx;
             const double gx = xp->gamma;
-            if (!(gx > 0.0)) { status = 2; break; }
-            if (idx >= 6LL * n) { status = 1; break; }
             d = (int)(idx % 6);
             j = (int)((idx / 6) % ny);
             i = (int)((idx / 6) / ny);
@@ -564,6 +561,21 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
                 b_cnt += (double)__popcll(m);
             }
         }
+    }
+    if (!(wv == 0 && h < my_hops && status == 0)) break;
+    {
+        // ---- exact path for hop h: publish the keys this wave stored, wake the helpers, replay the
+        // reference together
+        const double rho = readlane_f64(rho_v, (int)(h & 63));
+        __threadfence_block();
+        if (lane == 0) { *(volatile double*)&ctl->rho = rho; *(volatile int*)&ctl->seq = ++seq_sent; }
+        else ++seq_sent;
+        exact_select_par(keys_g, p.table, n, rho, xp);
+        ++n_exact;
+        if (!(xp->gamma > 0.0)) { status = 2; break; }
+        if (xp->idx >= 6LL * n) { status = 1; break; }
+        ex_have = true;
+    }
     }
     if (tid == 0) { *(volatile int*)&ctl->stop = 1; *(volatile int*)&ctl->seq = seq_sent + 1; }
     __syncthreads();
