@@ -81,7 +81,6 @@ struct HopParams {
 // drain vmcnt and stall on the deferred tag load.)
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
-struct ExactPick { long idx; double gamma, c, cprev; };
 
 // Literal restatement of hex_LiCoO2_kmc.py:486-492 on the stale-key state:
 // gamma with np.sum's association, strictly sequential cumsum, first index whose
@@ -94,7 +93,6 @@ __device__ __noinline__ void exact_select(const uint32_t* key, const double* tab
     exact_select_par_impl<1, 2, true>([=](long s) -> uint32_t { return key[s]; }, table, n, rho, sh);
 }
 
-#define KMC_LDS_FRAMES 16        // pairwise recursion depth for n6 <= 8192 per buffer is 7
 
 __host__ __device__ inline size_t hop_lds_layout(int nx, int n, size_t* off_blk, size_t* off_col, size_t* off_frames)
 {

@@ -15,10 +15,16 @@
 //     occupied, so its rates are zero in T and W).  Whether a site IS vacant is read from the column
 //     bitmaps when the replica is stored; the hop loop never asks
 //   * the column bitmaps' padding: {lo, hi, lo} = 12 B per column (816 B with the halo columns)
-//   * the exact path's scratch: in global memory (HopParams::xscratch), it runs once in ~1e8 hops
+//   * the exact path's state: in global memory (HopParams::xscratch), it runs once in ~1e8 hops
+//   * registers: the clock's draw is regenerated at the chunk flush, flush-only accumulators live in 96 B
+//     of LDS, tag registers are packed, loop-invariant addresses are recomputed
 // Selection is three levels: row (ballot over the per-lane row prefixes), quarter (three compares
 // in the lane that owns the row), entry (16 sites x 6 directions = 2 entries per lane on 48 lanes:
-// ONE 16-byte gather from the dense table per lane, a wave scan of the pair sums).
+// ONE 16-byte gather per lane from the pair table Tc2 -- or the dense table if the user's table does
+// not factor, template parameter COMPACT -- and a wave scan of the pair sums).
+// At 4 waves per SIMD the kernel is bound by vector-instruction issue rather than latency: uniform
+// decisions are branches or scalar code instead of per-lane selects, one-lane writes are v_writelane,
+// and a round trip through LDS is preferred to a handful of vector instructions.
 #pragma once
 #include "kmc_device.h"
 #include "kmc_hop_lds.h"
@@ -153,12 +159,18 @@ void hop_q64_kernel(HopParams p)
 
     const int grp_a = lane >> 3, grp_c = lane & 7;     // lane = 8 * a + c
     double Q0 = 0.0, Q1 = 0.0, Q2 = 0.0, Q3 = 0.0;     // lane i: the quarter sums of row i
-    for (int row = 0; row < 64; ++row) {
-        // quarter = tree8 over c of (W[site c] + W[site c + 8]): lanes 8..15 of each 16-lane row
-        const double x = load_w(q64_key(klo, khp, row * 64 + lane));
-        const double bs = group8_sum(x + dpp_f64<0x118, 0xF>(x));      // row_shr:8
-        const double q0 = readlane_f64(bs, 8), q1 = readlane_f64(bs, 24), q2 = readlane_f64(bs, 40), q3 = readlane_f64(bs, 56);
-        if (lane == row) { Q0 = q0; Q1 = q1; Q2 = q2; Q3 = q3; }
+    for (int row0 = 0; row0 < 64; row0 += 8) {
+        // quarter = tree8 over c of (W[site c] + W[site c + 8]): lanes 8..15 of each 16-lane row.
+        // Eight rows' gathers are issued together (one round trip of latency, not eight).
+        double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = load_w(q64_key(klo, khp, (row0 + k) * 64 + lane));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double bs = group8_sum(x[k] + dpp_f64<0x118, 0xF>(x[k]));      // row_shr:8
+            const double q0 = readlane_f64(bs, 8), q1 = readlane_f64(bs, 24), q2 = readlane_f64(bs, 40), q3 = readlane_f64(bs, 56);
+            if (lane == row0 + k) { Q0 = q0; Q1 = q1; Q2 = q2; Q3 = q3; }
+        }
     }
     ScanZero sz = {0, 0, 0, 0};
     double rowpre = wave_scan_incl_z((Q0 + Q1) + (Q2 + Q3), sz);
