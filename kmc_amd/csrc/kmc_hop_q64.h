@@ -88,6 +88,19 @@ __device__ __forceinline__ double wave_scan_incl_z(double x, ScanZero& z)
 
 static_assert(sizeof(ExactParShared) <= Q64_XSCRATCH, "exact-path scratch");
 
+// The kernel's parameters, re-read from the kernel-argument segment (scalar loads through the constant
+// cache) where they are used outside the hop loop.  Read once at the top they occupy ~50 scalar registers
+// for the whole kernel, and the hop loop then spills and refills its own scalars through vector lanes
+// (v_readlane / v_writelane: vector instructions, which is what the loop is short of).
+typedef const __attribute__((address_space(4))) HopParams* q64_params_ptr;
+__device__ __forceinline__ q64_params_ptr q64_cold_params()
+{
+    q64_params_ptr kp = (q64_params_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));           // opaque: the loads through it stay where they are written
+    return kp;
+}
+#define QP (q64_cold_params())
+
 // The reference's selection replayed exactly (hex_LiCoO2_kmc.py:486-492) by the replica's one wave:
 // kmc_exact_par.h with the keys read from the packed LDS planes.  ~50 us instead of the ~2.5 ms a
 // one-lane replay of the 24 576 entries takes -- which matters although only one hop in ~1e8 comes here:
@@ -114,11 +127,11 @@ void hop_q64_kernel(HopParams p)
     uint16_t* klo = reinterpret_cast<uint16_t*>(smem + Q64_KLO);
     uint32_t* khp = reinterpret_cast<uint32_t*>(smem + Q64_KHP);
     uint32_t* colw = reinterpret_cast<uint32_t*>(smem + Q64_COL);
-    ExactParShared* xsh = reinterpret_cast<ExactParShared*>(reinterpret_cast<unsigned char*>(p.xscratch) + (size_t)r * Q64_XSCRATCH);
+#define Q64_XSH (reinterpret_cast<ExactParShared*>(reinterpret_cast<unsigned char*>(QP->xscratch) + (size_t)r * Q64_XSCRATCH))
 
-    uint8_t* occ_g = p.occ + (size_t)r * 4096;
-    uint32_t* keys_g = p.keys + (size_t)r * 4096;
-    int4* tags_g = p.tags + (size_t)r * 4096;
+#define Q64_OCC_G (QP->occ + (size_t)r * 4096)
+#define Q64_KEYS_G (QP->keys + (size_t)r * 4096)
+#define Q64_TAGS_G (QP->tags + (size_t)r * 4096)
     const unsigned char* __restrict__ wsum_b = reinterpret_cast<const unsigned char*>(p.wsum);
     const unsigned char* __restrict__ table_b = reinterpret_cast<const unsigned char*>(p.table);
     auto load_w = [&](uint32_t k) -> double {
@@ -128,7 +141,10 @@ void hop_q64_kernel(HopParams p)
 
     // ---- load the replica ------------------------------------------------
     uint64_t cb = 0;                       // lane j owns column j's bitmap
-    for (int i = 0; i < 64; ++i) cb |= (uint64_t)(occ_g[i * 64 + lane] & 1u) << i;
+    {
+        const uint8_t* occ_g = Q64_OCC_G;
+        for (int i = 0; i < 64; ++i) cb |= (uint64_t)(occ_g[i * 64 + lane] & 1u) << i;
+    }
     // column c lives at dword 3 * (c + 2); columns 0, 1 are mirrored at 64, 65 and 62, 63 at -2, -1
     const bool col_mirrored = lane < 2 || lane >= 62;
     auto write_col = [&]() {
@@ -149,8 +165,9 @@ void hop_q64_kernel(HopParams p)
     write_col();
     for (int s = lane; s < 256; s += KMC_WAVE) khp[s] = 0u;
     wave_fence();
+    const uint32_t* keys_in = Q64_KEYS_G;
     for (int s = lane; s < 4096; s += KMC_WAVE) {
-        uint32_t k = keys_g[s];
+        uint32_t k = keys_in[s];
         k = k > 0x3FFFFu ? Q64_VAC : k;    // KMC_VACANT (0xFFFFFFFF) -> all neighbours Li (zero row)
         klo[s] = (uint16_t)k;
         atomicOr(&khp[s >> 4], (k >> 16) << ((s & 15) * 2));
@@ -179,19 +196,21 @@ void hop_q64_kernel(HopParams p)
 
     int status = 0;
     long long n_exact = 0, hops = 0;
-    unsigned long long hist_s = 0ull;      // 6 x 8-bit direction counters of the current chunk (scalar registers)
     long long* hist_l = reinterpret_cast<long long*>(smem + Q64_MISC);            // [6]
     double* time_l = reinterpret_cast<double*>(smem + Q64_MISC + 48);              // launch clock
     double* bstat_l = reinterpret_cast<double*>(smem + Q64_MISC + 56);             // last, sum, min, max, count
     if (lane < 6) hist_l[lane] = 0;
     if (lane == 0) time_l[0] = 0.0;
-    if (lane < 5) bstat_l[lane] = lane == 0 ? p.barrier[r * 5 + 0] : (lane == 2 ? 1e300 : (lane == 3 ? -1e300 : 0.0));
-    const long long hop0 = p.hops_done[r];
+    if (lane < 5) bstat_l[lane] = lane == 0 ? QP->barrier[r * 5 + 0] : (lane == 2 ? 1e300 : (lane == 3 ? -1e300 : 0.0));
+    const long long hop0 = QP->hops_done[r];
 
     // displacement tags: see kmc_hop_lds64.h (moved once per 64-hop chunk)
     // here tg_site and tg_vac share one register: site | vac << 16 (registers are the scarce resource at 4 waves per SIMD)
+    // Lane = one atom the chunk has moved: tg_sv = where it is now | the site it entered the chunk from << 16
+    // (0xFFFF: lane unused), tg_ow = the wraps gathered since, (wi + 64) << 8 | (wj + 64) << 16.  An atom
+    // that moves again keeps its lane; a new atom takes lane hl (its hop's number, free by construction).
+    // No loop-carried scalar masks: at 4 waves per SIMD the compiler spills those through vector lanes.
     int tg_sv = -1, tg_ow = 0;
-    unsigned long long tg_live = 0ull, tg_root = 0ull;
 
     // entry pick: lane = 3 * (site in quarter) + m, entries 2m and 2m+1 of that site; lanes >= 48 masked out
     const int ent_site = lane < 48 ? lane / 3 : 0;
@@ -221,7 +240,7 @@ void hop_q64_kernel(HopParams p)
     const bool force_exact = p.force_exact != 0;
     const bool presim = p.presim != 0;
 
-    const long long my_hops = p.n_hops_r ? p.n_hops_r[r] : p.n_hops;
+    const long long my_hops = QP->n_hops_r ? QP->n_hops_r[r] : QP->n_hops;
 #ifdef KMC_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
@@ -241,13 +260,13 @@ void hop_q64_kernel(HopParams p)
         auto draw_pair = [&](double& rho, double& u) {
             rho = 0.5; u = 1.0;
             if (lane < cnt) {
-                if (p.draws) {
-                    const double2 dv = reinterpret_cast<const double2*>(p.draws)[(size_t)r * p.n_hops + h0 + lane];
+                if (QP->draws) {
+                    const double2 dv = reinterpret_cast<const double2*>(QP->draws)[(size_t)r * QP->n_hops + h0 + lane];
                     rho = dv.x; u = dv.y;
                 } else {
                     const unsigned long long hh = (unsigned long long)(hop0 + h0 + lane);
                     u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r; c.w = KMC_STREAM_HOP;
-                    const u32x4 o = philox4x32_10(c, p.seed_lo, p.seed_hi);
+                    const u32x4 o = philox4x32_10(c, QP->seed_lo, QP->seed_hi);
                     rho = u53(o.x, o.y); u = u53_open0(o.z, o.w);
                 }
             }
@@ -270,7 +289,8 @@ void hop_q64_kernel(HopParams p)
             // ---- exact path (rare): the reference's selection replayed literally for hop h0 -----
             need_exact = false;
             wave_fence();
-            exact_select_q64(smem, p.table, readlane_f64(rho_v, 0), xsh);
+            ExactParShared* xsh = Q64_XSH;
+            exact_select_q64(smem, QP->table, readlane_f64(rho_v, 0), xsh);
             wave_fence();
             ++n_exact;
             if (!(xsh->gamma > 0.0)) { status = 2; run = 0; }
@@ -357,6 +377,7 @@ void hop_q64_kernel(HopParams p)
             if (ex_have) {
                 asm volatile("");
                 ex_have = false;
+                const ExactParShared* xsh = Q64_XSH;
                 const long ex_idx = xsh->idx;
                 const double g = xsh->gamma;
                 const double pn = xsh->c_found / g - xsh->cprev_found / g;      // the reference's own expression (:497)
@@ -460,25 +481,22 @@ void hop_q64_kernel(HopParams p)
                 }
             }
             // ---- book-keeping that nothing in this hop waits for runs while the gathers are in flight
-            hist_s += 1ull << (8 * d);
             writelane5(gam_lo, gam_hi, pn_lo, pn_hi, idx_v, __double2loint(gamma), __double2hiint(gamma),
                        pnum_lo, pnum_hi, idx | exact_flag, hl);
             ++hops;
             // tag move (:521-528): registers only, memory is touched at the chunk flush
             if (!presim) {
-                const unsigned long long m = ballot64((tg_sv & 0xFFFF) == s_src) & tg_live;
-                // tg_ow = origin lane | (wi + 64) << 8 | (wj + 64) << 16; |w| <= 64 inside a chunk
-                int ow = hl | (64 << 8) | (64 << 16);
+                const unsigned long long m = ballot64((tg_sv & 0xFFFF) == s_src);
+                const int wrap = ((ie >> 6) << 8) + ((je >> 6) << 16);      // floor(ie / 64) = -1, 0, +1
                 if (m) {
-                    // the atom came with an earlier hop of this chunk: inherit its origin and wraps
-                    ow = __builtin_amdgcn_readlane(tg_ow, __ffsll((long long)m) - 1);
-                    tg_live &= ~m;
+                    asm volatile("");              // the atom came with an earlier hop of this chunk
+                    const int lm = __ffsll((long long)m) - 1;
+                    const int osv = __builtin_amdgcn_readlane(tg_sv, lm), oow = __builtin_amdgcn_readlane(tg_ow, lm);
+                    writelane2(tg_sv, tg_ow, (osv & (int)0xFFFF0000) | s_dst, oow + wrap, lm);
                 } else {
-                    tg_root |= 1ull << hl;                       // its tag is still in memory, at s_src
+                    asm volatile("");              // its tag is still in memory, at s_src
+                    writelane2(tg_sv, tg_ow, s_dst | (s_src << 16), (64 << 8) + (64 << 16) + wrap, hl);
                 }
-                ow += ((ie >> 6) << 8) + ((je >> 6) << 16);      // wrap: floor(ie / 64) = -1, 0, +1
-                writelane2(tg_sv, tg_ow, s_dst | (s_src << 16), ow, hl);
-                tg_live |= 1ull << hl;
             }
             const double sumA = group8_sum(wA0 + wA1);
             KMC_STAMP(4);
@@ -518,29 +536,34 @@ void hop_q64_kernel(HopParams p)
         }
         // ---- flush the chunk: clock, trace, barrier diagnostics ----------------------
         done = hl;                          // hops of this chunk that executed
-        if (lane < 6) hist_l[lane] += (long long)((hist_s >> (8 * lane)) & 255ull);
-        hist_s = 0ull;
-        if (!presim && tg_root) {
-            const int tg_site = tg_sv & 0xFFFF, tg_vac = (int)((unsigned)tg_sv >> 16);
+        {
+            // direction histogram (:535) from the recorded indices, six ballots per chunk
+            const int dl = lane < done ? (idx_v & 0x3FFFFFFF) % 6 : -1;
+            int mine = 0;
+#pragma unroll
+            for (int dd = 0; dd < 6; ++dd) {
+                const int c = __popcll(ballot64(dl == dd));
+                mine = lane == dd ? c : mine;
+            }
+            if (lane < 6) hist_l[lane] += (long long)mine;
+        }
+        const unsigned long long tg_used = presim ? 0ull : ballot64((tg_sv & 0xFFFF) != 0xFFFF);
+        if (tg_used) {
             // ---- move the chunk's tags: memory still holds the state before the chunk --------
-            int4 tg_val = make_int4(0, 0, 0, 0);
-            if ((tg_root >> lane) & 1ull) tg_val = tags_g[tg_vac];
-            const bool is_live = (tg_live >> lane) & 1ull;
-            const int site_l = is_live ? tg_site : -1;
-            // a root's home site is vacant now unless a live atom sits on it, i.e. unless the site is occupied:
-            // one read of the column bitmaps instead of a loop over the roots
+            const int tg_site = tg_sv & 0xFFFF, tg_vac = (int)((unsigned)tg_sv >> 16);
+            int4* tags_g = Q64_TAGS_G;
+            const bool used = (tg_used >> lane) & 1ull;
+            int4 tv = make_int4(0, 0, 0, 0);
+            if (used) tv = tags_g[tg_vac];
+            // the site an atom left is vacant now unless a moved atom sits on it, i.e. unless it is occupied:
+            // one read of the column bitmaps
             const uint32_t hw = colw[3 * ((tg_vac & 63) + 2) + ((tg_vac >> 11) & 1)];
             const bool home_empty = ((hw >> ((tg_vac >> 6) & 31)) & 1u) == 0u;
-            const unsigned long long vac = ballot64(home_empty) & tg_root;
-            const int src = (tg_ow & 63) << 2;
-            int4 tv;
-            tv.x = __builtin_amdgcn_ds_bpermute(src, tg_val.x);
-            tv.y = __builtin_amdgcn_ds_bpermute(src, tg_val.y);
-            tv.z = __builtin_amdgcn_ds_bpermute(src, tg_val.z) + (((tg_ow >> 8) & 255) - 64);
-            tv.w = __builtin_amdgcn_ds_bpermute(src, tg_val.w) + (((tg_ow >> 16) & 255) - 64);
-            if (is_live) tags_g[tg_site] = tv;
-            if ((vac >> lane) & 1ull) tags_g[tg_vac] = make_int4(-1, 0, 0, 0);
-            tg_live = 0ull; tg_root = 0ull;        // stale tg_sv entries are masked by tg_live
+            tv.z += ((tg_ow >> 8) & 255) - 64;
+            tv.w += ((tg_ow >> 16) & 255) - 64;
+            if (used) tags_g[tg_site] = tv;
+            if (used && home_empty) tags_g[tg_vac] = make_int4(-1, 0, 0, 0);
+            tg_sv = -1;
         }
         const double gam_v = __hiloint2double(gam_hi, gam_lo), pn_v = __hiloint2double(pn_hi, pn_lo);
         if (!presim) {
@@ -551,7 +574,7 @@ void hop_q64_kernel(HopParams p)
             if (lane == 0) time_l[0] += tsum;
         }
         // a stopped replica fills the rest of its trace with -1; otherwise later chunks write the hops not done here
-        if (p.sel && lane < (status != 0 ? cnt : done)) p.sel[(size_t)r * p.n_hops + h0 + lane] = lane < done ? (idx_v & 0x3FFFFFFF) : -1;
+        if (QP->sel && lane < (status != 0 ? cnt : done)) QP->sel[(size_t)r * QP->n_hops + h0 + lane] = lane < done ? (idx_v & 0x3FFFFFFF) : -1;
         {
             const bool has = lane < done && (idx_v & 0x3FFFFFFF) != 0;           // :495
             const double pd_v = (idx_v & (1 << 30)) ? 1.0 : gam_v;
@@ -572,37 +595,39 @@ void hop_q64_kernel(HopParams p)
                 }
             }
         }
-        if (status != 0 && p.sel) {
-            for (long long hh = h0 + KMC_WAVE + lane; hh < p.n_hops; hh += KMC_WAVE)
-                p.sel[(size_t)r * p.n_hops + hh] = -1;
+        if (status != 0 && QP->sel) {
+            for (long long hh = h0 + KMC_WAVE + lane; hh < QP->n_hops; hh += KMC_WAVE)
+                QP->sel[(size_t)r * QP->n_hops + hh] = -1;
         }
     }
     // ---- store the replica --------------------------------------------------------------
     wave_fence();
+    uint8_t* occ_g = Q64_OCC_G;
+    uint32_t* keys_g = Q64_KEYS_G;
     for (int i = 0; i < 64; ++i) occ_g[i * 64 + lane] = (uint8_t)((cb >> i) & 1ull);
     for (int s = lane; s < 4096; s += KMC_WAVE) {
         // site s = (row s >> 6, column lane): its occupancy is a bit of this lane's own bitmap
         keys_g[s] = ((cb >> (s >> 6)) & 1ull) ? q64_key(klo, khp, s) : KMC_VACANT;
     }
-    if (lane < 6) p.hist[r * 6 + lane] += hist_l[lane];
+    if (lane < 6) QP->hist[r * 6 + lane] += hist_l[lane];
     const double b_stat = lane < 5 ? bstat_l[lane] : 0.0;
     if (lane == 0) {
         const double time_acc = time_l[0];
-        p.time_total[r] += time_acc;
-        p.step_time[r] = time_acc;
-        p.gamma[r] = gamma;
-        p.hops_done[r] = hop0 + hops;
-        p.n_exact[r] += n_exact;
-        p.status[r] |= status;
+        QP->time_total[r] += time_acc;
+        QP->step_time[r] = time_acc;
+        QP->gamma[r] = gamma;
+        QP->hops_done[r] = hop0 + hops;
+        QP->n_exact[r] += n_exact;
+        QP->status[r] |= status;
 #ifdef KMC_STAMPS
-        if (p.stamps)
-            for (int k = 0; k < 8; ++k) p.stamps[r * 8 + k] = (long long)st_acc[k];
+        if (QP->stamps)
+            for (int k = 0; k < 8; ++k) QP->stamps[r * 8 + k] = (long long)st_acc[k];
 #endif
     }
-    if (lane == 0) p.barrier[r * 5 + 0] = b_stat;
-    if (lane == 1 || lane == 4) p.barrier[r * 5 + lane] += b_stat;
-    if (lane == 2) p.barrier[r * 5 + 2] = fmin(p.barrier[r * 5 + 2], b_stat);
-    if (lane == 3) p.barrier[r * 5 + 3] = fmax(p.barrier[r * 5 + 3], b_stat);
+    if (lane == 0) QP->barrier[r * 5 + 0] = b_stat;
+    if (lane == 1 || lane == 4) QP->barrier[r * 5 + lane] += b_stat;
+    if (lane == 2) QP->barrier[r * 5 + 2] = fmin(QP->barrier[r * 5 + 2], b_stat);
+    if (lane == 3) QP->barrier[r * 5 + 3] = fmax(QP->barrier[r * 5 + 3], b_stat);
 }
 
 }  // namespace kmc
