@@ -237,7 +237,7 @@ void hop_q64_kernel(HopParams p)
     const int wm_ni0 = p.window_mode == 0 ? 4 : 5;
     const int wm_nj0 = p.window_mode == 0 ? 4 : (p.window_mode == 1 ? 6 : 5);
     const double mfac = p.mfac;
-    const bool force_exact = p.force_exact != 0;
+    const unsigned long long ok_mask = p.force_exact != 0 ? 0ull : ~0ull;     // kmc_set_debug: every hop through the exact path
     const bool presim = p.presim != 0;
 
     const long long my_hops = QP->n_hops_r ? QP->n_hops_r[r] : QP->n_hops;
@@ -365,7 +365,9 @@ void hop_q64_kernel(HopParams p)
                 pnum_lo = __builtin_amdgcn_readlane(__double2loint(rr.y), el);
                 pnum_hi = __builtin_amdgcn_readlane(__double2hiint(rr.y), el);
             }
-            bool ok = ((me & mok & (0ull - me)) != 0ull) && !force_exact;   // lowest set bit of me certified
+            // lowest set bit of me certified?  (scalar integer logic: as a bool the compiler rebuilds it per lane)
+            unsigned long long cert = me & mok & (0ull - me) & ok_mask;
+            asm("" : "+s"(cert));
             int j, d, i_sel = i;
             int exact_flag = 0;
             {
@@ -373,7 +375,7 @@ void hop_q64_kernel(HopParams p)
                 j = q * 16 + es;
                 d = 2 * (el - 3 * es) + snd;
             }
-            if (!ok && !ex_have) { need_exact = true; break; }      // the chunk ends here
+            if (cert == 0ull && !ex_have) { need_exact = true; break; }      // the chunk ends here
             if (ex_have) {
                 asm volatile("");
                 ex_have = false;
@@ -509,23 +511,21 @@ void hop_q64_kernel(HopParams p)
                 const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(sumA));
                 const double nA = __hiloint2double(hi, lo);
                 // qa is uniform: a branch and one select instead of four selects
-                switch (qa) {
-                case 0: asm volatile(""); Q0 = take ? nA : Q0; break;
-                case 1: asm volatile(""); Q1 = take ? nA : Q1; break;
-                case 2: asm volatile(""); Q2 = take ? nA : Q2; break;
-                default: asm volatile(""); Q3 = take ? nA : Q3; break;
-                }
+                // (four separate uniform tests rather than a switch: each updates its register in place, a
+                // switch makes the compiler copy the others around)
+                if (qa == 0) { asm volatile(""); Q0 = take ? nA : Q0; }
+                if (qa == 1) { asm volatile(""); Q1 = take ? nA : Q1; }
+                if (qa == 2) { asm volatile(""); Q2 = take ? nA : Q2; }
+                if (qa == 3) { asm volatile(""); Q3 = take ? nA : Q3; }
                 if (two) {
                     const double sumB = group8_sum(wB0 + wB1);
                     const int lob = __builtin_amdgcn_ds_bpermute(src, __double2loint(sumB));
                     const int hib = __builtin_amdgcn_ds_bpermute(src, __double2hiint(sumB));
                     const double nB = __hiloint2double(hib, lob);
-                    switch (qb) {
-                    case 0: asm volatile(""); Q0 = take ? nB : Q0; break;
-                    case 1: asm volatile(""); Q1 = take ? nB : Q1; break;
-                    case 2: asm volatile(""); Q2 = take ? nB : Q2; break;
-                    default: asm volatile(""); Q3 = take ? nB : Q3; break;
-                    }
+                    if (qb == 0) { asm volatile(""); Q0 = take ? nB : Q0; }
+                    if (qb == 1) { asm volatile(""); Q1 = take ? nB : Q1; }
+                    if (qb == 2) { asm volatile(""); Q2 = take ? nB : Q2; }
+                    if (qb == 3) { asm volatile(""); Q3 = take ? nB : Q3; }
                 }
             }
             wave_fence();
