@@ -496,3 +496,42 @@ def test_large_lattice_1024(kmc, tables, dense):
         assert (keys != fresh).mean() < 0.2                                  # stale keys exist but are a minority
         g = eng.gamma_exact()[0]
         np.testing.assert_allclose(eng.scalars()['gamma'][0], g, rtol=RTOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('nx,ny', [(64, 64), (30, 30), (70, 66)])
+def test_per_replica_hop_counts(kmc, tables, nx, ny):
+    """kmc_run_counts (the concentration sweep: int(n x) hops per replica and KMC step) leaves replica k
+    exactly where kmc_run(counts[k]) leaves it: draws are keyed by (seed, replica, hop number), so the
+    state after c hops does not depend on how many hops the neighbours run.  Counts straddle the
+    64-hop chunks of the kernels (0, 1, 63, 64, 65) -- 64 x 64 is the 16-per-CU kernel, 30 x 30 the
+    any-size LDS kernel, 70 x 66 the large-lattice kernel."""
+    counts = np.array([0, 1, 63, 64, 65, 200, 129], dtype=np.int64)
+    R, seed = len(counts), 77
+
+    def prepared():
+        eng = make_engine(kmc, tables, R, nx, ny)
+        eng.fill_random(np.linspace(0.3, 0.7, R), 5)
+        eng.rates_full()
+        eng.run(150, presim=True, seed=seed)
+        eng.init_displacements()
+        return eng
+
+    def state(eng):
+        sc, st = eng.scalars(), eng.status()
+        return (eng.get_lattice(), eng.get_keys(), eng.get_displacements(), sc['time'], sc['step_time'], sc['gamma'],
+                sc['hist'], st['hops_done'], st['status'])
+
+    with prepared() as eng:
+        eng.run_counts(counts, presim=False, seed=seed + 1)
+        got = state(eng)
+    for c in np.unique(counts):
+        with prepared() as eng:
+            if c:
+                eng.run(int(c), presim=False, seed=seed + 1)
+            want = state(eng)
+        for k in np.nonzero(counts == c)[0]:
+            for a, b in zip(got, want):
+                if c == 0 and a is got[4]:
+                    continue                 # step_time of a replica that did not run keeps the presimulation's
+                assert np.array_equal(a[k], b[k]), (nx, ny, int(c), int(k))
