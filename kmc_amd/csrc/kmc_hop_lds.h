@@ -28,10 +28,11 @@
 // Exactness.  The reference picks the first idx with fl(cumsum_seq[idx]/np.sum) >= rho.
 // Our running sums associate differently, so the pick is accepted only if t is
 // further than a rigorous bound M from both neighbouring boundaries (lo, hi):
-//     M = gamma * (6n + 256) * 2^-53 * 1.001
-//   6n      rounding of the reference's sequential sum (k <= 6n terms)
-//   256     our own <= 40 roundings (5 per W, 3 per block, 7 per row, 6 + 3 + 6 in the
-//           scans), gamma vs np.sum, fl(rho*gamma), the 2u of fl(c/gamma) >= rho
+//     M = gamma * (6n (1 + 1/8192) + 512) * 2^-53 * 1.001         (HopParams::mfac, set by the host)
+//   6n        rounding of the reference's sequential sum (k <= 6n terms)
+//   6n/8192   np.sum adds its 8192-element buffers left to right
+//   512       our own <= 40 roundings (5 per W, 3 per block, 7 per row, 6 + 3 + 6 in the scans), the
+//             ~30 roundings inside one np.sum buffer, fl(rho*gamma), the 2u of fl(c/gamma) >= rho
 // Otherwise (about 3e-8 of hops at 64x64) exact_select() replays the reference.
 #pragma once
 #include "kmc_device.h"
@@ -44,7 +45,7 @@ struct HopParams {
     long long n_hops;            // hops per replica (stride of draws / sel)
     const long long* n_hops_r;   // [R] per-replica hop counts (<= n_hops) or null
     int presim, force_exact;
-    double mfac;                 // (6n + 256) * 2^-53 * 1.001 * margin_scale
+    double mfac;                 // (6n (1 + 1/8192) + 512) * 2^-53 * 1.001 * margin_scale
     const double* table;         // [2^18][6]
     const double* wsum;          // [2^18]
     const double* tcompact;      // [6][2^13] per-direction compact table (hop_lds64_kernel<true>) or null
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
                 }
             }
             if (!ok) {
-                // ---- exact sequential path (rare) --------------------------------
+                // ---- exact path (rare): the reference replayed by the whole wave -----
                 wave_fence();
                 exact_select(key, p.table, n, rho, xsh);
                 wave_fence();

@@ -242,7 +242,7 @@ void hop_lds64_kernel(HopParams p)
                 d = el - 6 * es;
             }
             if (!ok) {
-                // ---- exact sequential path (rare) --------------------------------
+                // ---- exact path (rare): the reference replayed by the whole wave -----
                 wave_fence();
                 exact_select64(smem, p.table, readlane_f64(rho_v, hl), xsh);
                 wave_fence();
