@@ -75,8 +75,8 @@ def cpu_baseline(np, base512, seed=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--replicas', type=int, default=REPLICAS_PER_GPU, help='replicas per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
