@@ -535,3 +535,33 @@ def test_per_replica_hop_counts(kmc, tables, nx, ny):
                 if c == 0 and a is got[4]:
                     continue                 # step_time of a replica that did not run keeps the presimulation's
                 assert np.array_equal(a[k], b[k]), (nx, ny, int(c), int(k))
+
+
+@pytest.mark.gpu
+def test_full_size_ensemble_two_kernels(kmc, tables):
+    """BASELINE's headline size -- 4096 replicas of 64 x 64, the bench configuration, one full round of
+    16 workgroups per CU -- through the default 16-per-CU kernel and through the 8-per-CU kernel:
+    every lattice, key, displacement tag and histogram identical, clocks equal to rounding, nobody
+    stopped.  (The 8-per-CU kernel is pinned to the oracle by the trajectory tests above.)"""
+    R, hp, hs, seed = 4096, 2048, 4096, 2024
+    conc = np.tile(np.linspace(0.1, 0.9, 9), R // 9 + 1)[:R]
+    out = []
+    for which in (0, 2):
+        with make_engine(kmc, tables, R, 64, 64) as eng:
+            eng.set_hop_kernel(which=which)
+            eng.fill_random(conc, 31)
+            eng.rates_full()
+            eng.run(hp, presim=True, seed=seed)
+            eng.init_displacements()
+            eng.run(hs, presim=False, seed=seed + 1)
+            sc, st = eng.scalars(), eng.status()
+            out.append((eng.get_lattice(), eng.get_keys(), eng.get_displacements(), sc['hist'], st['hops_done'], st['status'],
+                        sc['time'], sc['gamma']))
+    a, b = out
+    for k in range(6):
+        assert np.array_equal(a[k], b[k]), k
+    assert not a[5].any() and (a[4] == hp + hs).all()
+    np.testing.assert_allclose(a[6], b[6], rtol=1e-13)
+    np.testing.assert_allclose(a[7], b[7], rtol=1e-13)
+    # conservation: hops move atoms, they never create or destroy them
+    assert np.array_equal(a[0].reshape(R, -1).sum(axis=1), (a[2].reshape(R, -1, 4)[:, :, 0] >= 0).sum(axis=1))
