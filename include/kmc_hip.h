@@ -157,10 +157,10 @@ int kmc_lds_bytes(kmc_ctx* ctx);
  * table given to kmc_set_hex_table that does not factor returns 0 and keeps the dense gather.
  * No counterpart in the reference. */
 int kmc_table_is_compact(kmc_ctx* ctx);
-/* Choice of hop kernel (tests compare them): which = 0 the default for the lattice size; 1 the generic
- * kernel (any-size LDS kernel, or the global-memory kernel for large lattices); 2 for 64 x 64 replicas the
- * 8-replicas-per-CU kernel (kmc_hop_lds64.h) instead of the default 16-per-CU one (kmc_hop_q64.h).
- * No counterpart in the reference. */
+/* Choice of hop kernel (tests compare them): which = 0 the default for the lattice size and replica count;
+ * 1 the generic kernel (any-size LDS kernel, or the global-memory kernel for large lattices); for 64 x 64
+ * replicas 2 = the 8-replicas-per-CU kernel (kmc_hop_lds64.h), 3 = the 16-per-CU kernel (kmc_hop_q64.h);
+ * the default is 3.  No counterpart in the reference. */
 int kmc_set_hop_kernel(kmc_ctx* ctx, int which);
 /* profiling builds only (-DKMC_STAMPS): cycles [R][8] the last kmc_run spent per hop segment, measured
  * with s_memtime; any other build returns KMC_ESTATE.  No counterpart in the reference. */

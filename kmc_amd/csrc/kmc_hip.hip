@@ -32,6 +32,7 @@ struct kmc_ctx {
     bool lds_path;
     bool lds64;            // 64 x 64 replicas: the specialised kernels of kmc_hop_lds64.h / kmc_hop_q64.h
     bool q64;              // ... the 16-replicas-per-CU kernel (kmc_hop_q64.h) rather than the 8-per-CU one
+    bool q64_auto;         // what kmc_set_hop_kernel(ctx, 0) picks
     void* xscratch;        // [R][Q64_XSCRATCH] exact-path scratch of hop_q64_kernel
     bool big_ok, use_big;  // larger lattices whose bitmaps fit LDS: kmc_hop_big.h (else kmc_hop_global.h)
     BigGeom geom;
@@ -498,7 +499,10 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     CREATE_CHK(hipMemsetAsync(c->n_exact, 0, c->R * 8, c->stream));
     CREATE_CHK(hipMemsetAsync(c->status, 0, c->R * 4, c->stream));
     c->lds64 = c->lds_path && nx == 64 && ny == 64;
-    c->q64 = c->lds64;
+    // The 16-per-CU kernel is the default at every replica count: up to 8 replicas per CU the two kernels are
+    // within 2 % of each other (scripts/kernel_crossover.py), beyond it wins by up to 1.5x.
+    c->q64_auto = true;
+    c->q64 = c->lds64 && c->q64_auto;
     if (c->lds64) CREATE_CHK(hipMalloc(&c->xscratch, (size_t)c->R * Q64_XSCRATCH));
     if (c->lds_path) {
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, K64_LDS_BYTES));
@@ -580,14 +584,14 @@ int kmc_lds_bytes(kmc_ctx* c)
     return c->lds64 ? (c->q64 ? Q64_LDS_BYTES : K64_LDS_BYTES) : (int)host_hop_lds_bytes(c->nx, c->n);
 }
 
-// which = 0: the default kernel for the lattice size; 1: the generic kernel (any size); 2: for 64 x 64
-// replicas, the 8-replicas-per-CU kernel (kmc_hop_lds64.h) instead of the 16-per-CU one (kmc_hop_q64.h)
+// which = 0: the default kernel for the lattice size and replica count; 1: the generic kernel (any size);
+// 2 / 3: for 64 x 64 replicas, the 8-replicas-per-CU kernel (kmc_hop_lds64.h) / the 16-per-CU one (kmc_hop_q64.h)
 int kmc_set_hop_kernel(kmc_ctx* c, int which)
 {
     CTXCHK(c);
-    if (which < 0 || which > 2) return fail(c, KMC_EINVAL, "kmc_set_hop_kernel: which must be 0, 1 or 2");
+    if (which < 0 || which > 3) return fail(c, KMC_EINVAL, "kmc_set_hop_kernel: which must be 0, 1, 2 or 3");
     c->lds64 = c->lds_path && c->nx == 64 && c->ny == 64 && which != 1;
-    c->q64 = c->lds64 && which == 0;
+    c->q64 = c->lds64 && (which == 3 || (which == 0 && c->q64_auto));
     c->use_big = c->big_ok && which != 1;
     return KMC_OK;
 }

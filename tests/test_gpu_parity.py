@@ -217,7 +217,16 @@ def test_random_ensemble_vs_oracle(kmc, tables, dense, cfg):
     occ = np.stack([(rs.rand(nx, ny) < c).astype(np.int8) for c in conc])
     d_pre = np.stack([rs.rand(R, hp), np.ones((R, hp))], axis=-1)
     d_sim = rs.rand(R, hs, 2)
+    oracle = [_oracle_run(occ[r], dense, mode, d_pre[r], d_sim[r], conc[r]) for r in range(R)]
+    # 64 x 64 has two kernels (16 replicas per CU, the default, and 8): both
+    for which in ((3, 2) if (nx, ny) == (64, 64) else (0,)):
+        _ensemble_vs_oracle(kmc, tables, cfg, which, occ, d_pre, d_sim, oracle)
+
+
+def _ensemble_vs_oracle(kmc, tables, cfg, which, occ, d_pre, d_sim, oracle):
+    nx, ny, R, hp, hs, mode, mscale = cfg
     with make_engine(kmc, tables, R, nx, ny, mode) as eng:
+        eng.set_hop_kernel(which=which)
         eng.set_debug(force_exact=False, margin_scale=mscale)
         eng.set_lattice(occ)
         eng.rates_full()
@@ -229,7 +238,7 @@ def test_random_ensemble_vs_oracle(kmc, tables, dense, cfg):
         ds, dj, _ = eng.diffusion(occ.reshape(R, -1).mean(axis=1))
         gex = eng.gamma_exact()
     for r in range(R):
-        rep, idx = _oracle_run(occ[r], dense, mode, d_pre[r], d_sim[r], conc[r])
+        rep, idx = oracle[r]
         assert np.array_equal(got_idx[r], idx), 'replica %d' % r
         assert np.array_equal(lat[r], rep.occ)
         assert np.array_equal(tags[r], rep.tags)
@@ -260,7 +269,7 @@ def test_lds64_kernel_equals_generic_kernel(kmc, tables, mode):
     R, hp, hs, seed = 72, 4096 + 37, 10000, 0xC0FFEE
     conc = np.repeat(np.linspace(0.1, 0.9, 9), 8)
     out = []
-    for which in (0, 2, 1):                      # default (q64), lds64, generic
+    for which in (3, 2, 1):                      # q64, lds64, generic
         with make_engine(kmc, tables, R, 64, 64, mode) as eng:
             eng.set_hop_kernel(which=which)
             eng.fill_random(conc, 99)
@@ -296,24 +305,27 @@ def test_dense_table_that_does_not_factor(kmc, tables, dense):
     occ = np.stack([(rs.rand(64, 64) < c).astype(np.int8) for c in (0.3, 0.5, 0.7)])
     d_pre = np.stack([rs.rand(R, hp), np.ones((R, hp))], axis=-1)
     d_sim = rs.rand(R, hs, 2)
-    with kmc.KMCEngine(R, 64, 64) as eng:
-        eng.set_base_table(tables[0]['base512_normcons'], kmc.tables.dumbbell_rate())
-        assert eng.table_is_compact()
-        eng.set_hex_table(dense2)
-        assert not eng.table_is_compact()
-        eng.set_lattice(occ)
-        eng.rates_full()
-        i1 = eng.run(hp, presim=True, draws=d_pre, want_trace=True)
-        eng.init_displacements()
-        i2 = eng.run(hs, presim=False, draws=d_sim, want_trace=True)
-        got, lat, tags, sc = np.concatenate([i1, i2], axis=1), eng.get_lattice(), eng.get_reference_tags(), eng.scalars()
-        eng.set_hex_table(dense)
-        assert eng.table_is_compact()
-    for r in range(R):
-        rep, idx = _oracle_run(occ[r], dense2, 'hex_ref', d_pre[r], d_sim[r], None)
-        assert np.array_equal(got[r], idx)
-        assert np.array_equal(lat[r], rep.occ) and np.array_equal(tags[r], rep.tags)
-        np.testing.assert_allclose(sc['time'][r], rep.time.value, rtol=RTOL)
+    oracle = [_oracle_run(occ[r], dense2, 'hex_ref', d_pre[r], d_sim[r], None) for r in range(R)]
+    for which in (3, 2):                                         # both 64 x 64 kernels have a dense variant
+        with kmc.KMCEngine(R, 64, 64) as eng:
+            eng.set_hop_kernel(which=which)
+            eng.set_base_table(tables[0]['base512_normcons'], kmc.tables.dumbbell_rate())
+            assert eng.table_is_compact()
+            eng.set_hex_table(dense2)
+            assert not eng.table_is_compact()
+            eng.set_lattice(occ)
+            eng.rates_full()
+            i1 = eng.run(hp, presim=True, draws=d_pre, want_trace=True)
+            eng.init_displacements()
+            i2 = eng.run(hs, presim=False, draws=d_sim, want_trace=True)
+            got, lat, tags, sc = np.concatenate([i1, i2], axis=1), eng.get_lattice(), eng.get_reference_tags(), eng.scalars()
+            eng.set_hex_table(dense)
+            assert eng.table_is_compact()
+        for r in range(R):
+            rep, idx = oracle[r]
+            assert np.array_equal(got[r], idx)
+            assert np.array_equal(lat[r], rep.occ) and np.array_equal(tags[r], rep.tags)
+            np.testing.assert_allclose(sc['time'][r], rep.time.value, rtol=RTOL)
 
 
 # ---------------------------------------------------------------- RNG streams / fill
@@ -511,6 +523,8 @@ def test_per_replica_hop_counts(kmc, tables, nx, ny):
 
     def prepared():
         eng = make_engine(kmc, tables, R, nx, ny)
+        if (nx, ny) == (64, 64):
+            eng.set_hop_kernel(which=3)
         eng.fill_random(np.linspace(0.3, 0.7, R), 5)
         eng.rates_full()
         eng.run(150, presim=True, seed=seed)
@@ -546,7 +560,7 @@ def test_full_size_ensemble_two_kernels(kmc, tables):
     R, hp, hs, seed = 4096, 2048, 4096, 2024
     conc = np.tile(np.linspace(0.1, 0.9, 9), R // 9 + 1)[:R]
     out = []
-    for which in (0, 2):
+    for which in (3, 2):
         with make_engine(kmc, tables, R, 64, 64) as eng:
             eng.set_hop_kernel(which=which)
             eng.fill_random(conc, 31)
