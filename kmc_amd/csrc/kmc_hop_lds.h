@@ -162,10 +162,12 @@ __global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
     double b_last = p.barrier[r * 5 + 0], b_sum = 0.0, b_min = 1e300, b_max = -1e300, b_cnt = 0.0;
     const long long hop0 = p.hops_done[r];
 
-    // deferred tag move (the load of one hop is consumed during the next)
-    bool pend = false;
-    int pend_src = 0, pend_dst = 0, pend_dwi = 0, pend_dwj = 0;
-    int4 pend_tag = make_int4(0, 0, 0, 0);
+    // Displacement tags (:521-528) move once per 64-hop chunk (issuing a vector store costs a wave ~120
+    // cycles, and the tag values never feed back into the dynamics).  Lane = one atom the chunk has moved:
+    // tg_sv = where it is now | the site it entered the chunk from << 16 (0xFFFF: lane unused), tg_ow = the
+    // wraps gathered since, (wi + 64) << 8 | (wj + 64) << 16.  An atom that moves again keeps its lane; a
+    // new atom takes lane hl (its hop's number within the chunk, free by construction).
+    int tg_sv = -1, tg_ow = 0;
 
     // per-lane constants of the 48-lane entry pick: lane = 6 * (site in block) + direction
     const int ent_site = (lane * 43) >> 8;             // lane / 6 for lane < 48
@@ -298,20 +300,17 @@ __global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
             }
             wave_fence();
             KMC_STAMP(3);
-            // ---- tag move, deferred by one hop (:521-528) ------------------------------
+            // ---- tag move (:521-528): registers only, memory is touched at the chunk flush -----
             if (!p.presim) {
-                if (lane == 0) {
-                    if (pend) {
-                        int4 tg = pend_tag;
-                        tg.z += pend_dwi; tg.w += pend_dwj;
-                        tags_g[pend_dst] = tg;
-                        tags_g[pend_src] = make_int4(-1, 0, 0, 0);
-                    }
-                    pend_tag = tags_g[s_src];
+                const unsigned long long m = __ballot((tg_sv & 0xFFFF) == s_src);
+                const int wrap = ((ie < 0 ? -1 : (ie >= nx ? 1 : 0)) << 8) + ((je < 0 ? -1 : (je >= ny ? 1 : 0)) << 16);
+                if (m) {                                 // the atom came with an earlier hop of this chunk
+                    const int lm = __ffsll((long long)m) - 1;
+                    const int osv = __builtin_amdgcn_readlane(tg_sv, lm), oow = __builtin_amdgcn_readlane(tg_ow, lm);
+                    if (lane == lm) { tg_sv = (osv & (int)0xFFFF0000) | s_dst; tg_ow = oow + wrap; }
+                } else if (lane == hl) {                 // its tag is still in memory, at s_src
+                    tg_sv = s_dst | (s_src << 16); tg_ow = (64 << 8) + (64 << 16) + wrap;
                 }
-                pend = true; pend_src = s_src; pend_dst = s_dst;
-                pend_dwi = ie < 0 ? -1 : (ie >= nx ? 1 : 0);
-                pend_dwj = je < 0 ? -1 : (je >= ny ? 1 : 0);
             }
             // ---- re-sum the touched blocks and rows -------------------------------------
             {
@@ -351,8 +350,25 @@ __global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
             gamma = readlane_f64(rowpre, 63);
             KMC_STAMP(5);
         }
-        // ---- flush the chunk: clock, trace, barrier diagnostics ----------------------
+        // ---- flush the chunk: tags, clock, trace, barrier diagnostics ----------------
         const int done = hl;                // hops of this chunk that executed
+        const unsigned long long tg_used = p.presim ? 0ull : __ballot((tg_sv & 0xFFFF) != 0xFFFF);
+        if (tg_used) {
+            // memory still holds the tags as they were before the chunk: every moved atom loads its own
+            // from the site it left, adds its wraps and stores it where it is now; a site that was left
+            // is vacant now unless it is occupied (then a moved atom sits on it and stores its tag there)
+            const bool used = (tg_used >> lane) & 1ull;
+            const int tg_site = tg_sv & 0xFFFF, tg_vac = used ? (int)((unsigned)tg_sv >> 16) : 0;
+            int4 tv = make_int4(0, 0, 0, 0);
+            if (used) tv = tags_g[tg_vac];
+            const int vi = tg_vac / ny, vj = tg_vac - vi * ny;
+            const bool home_empty = ((col[vj] >> vi) & 1ull) == 0ull;
+            tv.z += ((tg_ow >> 8) & 255) - 64;
+            tv.w += ((tg_ow >> 16) & 255) - 64;
+            if (used) tags_g[tg_site] = tv;
+            if (used && home_empty) tags_g[tg_vac] = make_int4(-1, 0, 0, 0);
+            tg_sv = -1;
+        }
         if (!p.presim) {
             const double dt = lane < done ? (-1.0 / gam_v) * log(u_v) : 0.0;      // :530
             time_acc += wave_sum(dt);
@@ -380,13 +396,7 @@ __global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
                 p.sel[(size_t)r * p.n_hops + hh] = -1;
         }
     }
-    // ---- finish the pending tag move, store the replica -------------------------------
-    if (!p.presim && pend && lane == 0) {
-        int4 tg = pend_tag;
-        tg.z += pend_dwi; tg.w += pend_dwj;
-        tags_g[pend_dst] = tg;
-        tags_g[pend_src] = make_int4(-1, 0, 0, 0);
-    }
+    // ---- store the replica ----------------------------------------------------------------
     wave_fence();
     if (lane < ny)
         for (int i = 0; i < nx; ++i) occ_g[i * ny + lane] = (uint8_t)((cb >> i) & 1ull);
