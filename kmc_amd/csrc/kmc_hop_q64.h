@@ -295,7 +295,13 @@ void hop_q64_kernel(HopParams p)
             ++n_exact;
             if (!(xsh->gamma > 0.0)) { status = 2; run = 0; }
             else if (xsh->idx >= 6L * 4096) { status = 1; run = 0; }
-            else ex_have = true;
+            else {
+                ex_have = true;
+                // rho <= 0 selects entry 0 whatever its rate (searchsorted left, B4): such a hop may leave a
+                // vacant site or land on an occupied one, which the chunk's tag tracking does not model.
+                // It runs as a chunk of its own: memory holds the true tags before and after it.
+                if (xsh->idx == 0) run = 1;
+            }
         }
         KMC_STAMP(0);
         for (; hl < run; ++hl) {
@@ -410,10 +416,12 @@ void hop_q64_kernel(HopParams p)
             const bool act = grp_a < n_i;
             const int qa = (j_lo & 63) >> 4, qb = ((j_lo + n_j - 1) & 63) >> 4;
             const bool two = qa != qb;                           // uniform
-            // the source bit is set and the destination bit clear: two flips under exec masks (the
-            // empty asm keeps them branches: as selects they cost four moves and four selects more)
-            if (lane == j) { asm volatile(""); cb ^= 1ull << ii; }
-            if (lane == jw) { asm volatile(""); cb ^= 1ull << iw; }
+            // two single-lane updates under exec masks (the empty asm keeps them branches: as selects they
+            // cost four moves and four selects more)
+            // (clear / set, not flips: with rho == 0 the reference "hops" entry 0 whatever its rate, B4, so the
+            // source may be vacant already and the destination occupied)
+            if (lane == j) { asm volatile(""); cb &= ~(1ull << ii); }
+            if (lane == jw) { asm volatile(""); cb |= 1ull << iw; }
             if (lane == j || lane == jw) write_col();
             wave_fence();
             KMC_STAMP(7);

@@ -365,18 +365,20 @@ def test_philox_stream_run_matches_injected(kmc, tables, dense):
 
 
 # ---------------------------------------------------------------- edges
-def test_selection_edges(kmc, tables, dense):
+@pytest.mark.parametrize('nx,ny,which', [(10, 10, 0), (64, 64, 3), (64, 64, 2), (70, 66, 0)],
+                         ids=['lds-10x10', 'q64', 'lds64', 'big-70x66'])
+def test_selection_edges(kmc, tables, dense, nx, ny, which):
     """rho == 0 picks index 0 (searchsorted left); rho above cumsum[-1]/gamma is the
     reference's IndexError -> the replica stops with KMC_ST_OVERFLOW; a lattice
-    with no possible hop stops with KMC_ST_ZERO_GAMMA.  """
-    nx = 10
+    with no possible hop stops with KMC_ST_ZERO_GAMMA.    Every hop-kernel family."""
     rs = np.random.RandomState(0)
-    occ = (rs.rand(3, nx, nx) < 0.5).astype(np.int8)
+    occ = (rs.rand(3, nx, ny) < 0.5).astype(np.int8)
     occ[2] = 1                                           # full lattice: gamma == 0
     draws = rs.rand(3, 40, 2)
     draws[0, 10, 0] = 0.0
     draws[1, 25, 0] = 1.0
-    with make_engine(kmc, tables, 3, nx) as eng:
+    with make_engine(kmc, tables, 3, nx, ny) as eng:
+        eng.set_hop_kernel(which=which)
         eng.set_lattice(occ)
         eng.rates_full()
         eng.init_displacements()
