@@ -173,6 +173,29 @@ __global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
     const int ent_site = (lane * 43) >> 8;             // lane / 6 for lane < 48
     const int ent_dir = lane - 6 * ent_site;
 
+    // Move the tracked tags to memory.  Called at every chunk's end, and around a hop with rho <= 0: that hop
+    // takes entry 0 whatever its rate, so it may leave a vacant site or land on an occupied one,
+    // which the tracking does not model -- it is made a tracking period of its own.
+    auto flush_tags = [&]() {
+        const unsigned long long tg_used = p.presim ? 0ull : __ballot((tg_sv & 0xFFFF) != 0xFFFF);
+        if (tg_used) {
+            // memory still holds the tags as they were before the chunk: every moved atom loads its own
+            // from the site it left, adds its wraps and stores it where it is now; a site that was left
+            // is vacant now unless it is occupied (then a moved atom sits on it and stores its tag there)
+            const bool used = (tg_used >> lane) & 1ull;
+            const int tg_site = tg_sv & 0xFFFF, tg_vac = used ? (int)((unsigned)tg_sv >> 16) : 0;
+            int4 tv = make_int4(0, 0, 0, 0);
+            if (used) tv = tags_g[tg_vac];
+            const int vi = tg_vac / ny, vj = tg_vac - vi * ny;
+            const bool home_empty = ((col[vj] >> vi) & 1ull) == 0ull;
+            tv.z += ((tg_ow >> 8) & 255) - 64;
+            tv.w += ((tg_ow >> 16) & 255) - 64;
+            if (used) tags_g[tg_site] = tv;
+            if (used && home_empty) tags_g[tg_vac] = make_int4(-1, 0, 0, 0);
+            tg_sv = -1;
+        }
+    };
+    bool tg_flush_after = false;
     const long long my_hops = p.n_hops_r ? p.n_hops_r[r] : p.n_hops;
 #ifdef KMC_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -260,6 +283,7 @@ __global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
                 i = (int)((idx / 6) / ny);
                 pnum = xsh->c_found / g - xsh->cprev_found / g;      // the reference's own expression (:497)
                 pden = 1.0;
+                if (idx == 0) { flush_tags(); tg_flush_after = true; }     // rho <= 0: see flush_tags
             }
             KMC_STAMP(2);
             const int s_src = i * ny + j;
@@ -311,6 +335,7 @@ __global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
                 } else if (lane == hl) {                 // its tag is still in memory, at s_src
                     tg_sv = s_dst | (s_src << 16); tg_ow = (64 << 8) + (64 << 16) + wrap;
                 }
+                if (tg_flush_after) { tg_flush_after = false; flush_tags(); }
             }
             // ---- re-sum the touched blocks and rows -------------------------------------
             {
@@ -352,23 +377,7 @@ __global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
         }
         // ---- flush the chunk: tags, clock, trace, barrier diagnostics ----------------
         const int done = hl;                // hops of this chunk that executed
-        const unsigned long long tg_used = p.presim ? 0ull : __ballot((tg_sv & 0xFFFF) != 0xFFFF);
-        if (tg_used) {
-            // memory still holds the tags as they were before the chunk: every moved atom loads its own
-            // from the site it left, adds its wraps and stores it where it is now; a site that was left
-            // is vacant now unless it is occupied (then a moved atom sits on it and stores its tag there)
-            const bool used = (tg_used >> lane) & 1ull;
-            const int tg_site = tg_sv & 0xFFFF, tg_vac = used ? (int)((unsigned)tg_sv >> 16) : 0;
-            int4 tv = make_int4(0, 0, 0, 0);
-            if (used) tv = tags_g[tg_vac];
-            const int vi = tg_vac / ny, vj = tg_vac - vi * ny;
-            const bool home_empty = ((col[vj] >> vi) & 1ull) == 0ull;
-            tv.z += ((tg_ow >> 8) & 255) - 64;
-            tv.w += ((tg_ow >> 16) & 255) - 64;
-            if (used) tags_g[tg_site] = tv;
-            if (used && home_empty) tags_g[tg_vac] = make_int4(-1, 0, 0, 0);
-            tg_sv = -1;
-        }
+        flush_tags();
         if (!p.presim) {
             const double dt = lane < done ? (-1.0 / gam_v) * log(u_v) : 0.0;      // :530
             time_acc += wave_sum(dt);

@@ -174,6 +174,36 @@ void hop_lds64_kernel(HopParams p)
     const bool force_exact = p.force_exact != 0;
     const bool presim = p.presim != 0;
 
+    // Move the tracked tags to memory (memory holds the tags as they were when tracking started).  Called at
+    // every chunk's end, and around a hop with rho <= 0: that hop takes entry 0 whatever its rate,
+    // so it may leave a vacant site or land on an occupied one, which the tracking does not model -- it is
+    // made a tracking period of its own.
+    auto flush_tags = [&]() {
+        if (!presim && tg_root) {
+            // ---- move the chunk's tags: memory still holds the state before the chunk --------
+            int4 tg_val = make_int4(0, 0, 0, 0);
+            if ((tg_root >> lane) & 1ull) tg_val = tags_g[tg_vac];
+            const bool is_live = (tg_live >> lane) & 1ull;
+            const int site_l = is_live ? tg_site : -1;
+            // a root's home site is vacant now unless a live atom sits on it
+            unsigned long long vac = 0ull;
+            for (unsigned long long rm = tg_root; rm; rm &= rm - 1ull) {
+                const int rl = __ffsll((long long)rm) - 1;
+                const int home = __builtin_amdgcn_readlane(tg_vac, rl);
+                if (ballot64(site_l == home) == 0ull) vac |= 1ull << rl;
+            }
+            const int src = (tg_ow & 63) << 2;
+            int4 tv;
+            tv.x = __builtin_amdgcn_ds_bpermute(src, tg_val.x);
+            tv.y = __builtin_amdgcn_ds_bpermute(src, tg_val.y);
+            tv.z = __builtin_amdgcn_ds_bpermute(src, tg_val.z) + (((tg_ow >> 8) & 255) - 64);
+            tv.w = __builtin_amdgcn_ds_bpermute(src, tg_val.w) + (((tg_ow >> 16) & 255) - 64);
+            if (is_live) tags_g[tg_site] = tv;
+            if ((vac >> lane) & 1ull) tags_g[tg_vac] = make_int4(-1, 0, 0, 0);
+            tg_live = 0ull; tg_root = 0ull; tg_site = -1;
+        }
+    };
+    bool tg_flush_after = false;
     const long long my_hops = p.n_hops_r ? p.n_hops_r[r] : p.n_hops;
 #ifdef KMC_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -256,6 +286,7 @@ void hop_lds64_kernel(HopParams p)
                 i_sel = (int)((idx / 6) >> 6);
                 pnum = xsh->c_found / g - xsh->cprev_found / g;      // the reference's own expression (:497)
                 exact_flag = 1 << 30;
+                if (idx == 0) { flush_tags(); tg_flush_after = true; }     // rho <= 0: see flush_tags
             }
             KMC_STAMP(2);
             const int ii = i_sel;
@@ -348,6 +379,7 @@ void hop_lds64_kernel(HopParams p)
                 ow += ((ie >> 6) << 8) + ((je >> 6) << 16);      // wrap: floor(ie / 64) = -1, 0, +1
                 if (lane == hl) { tg_site = s_dst; tg_ow = ow; tg_vac = s_src; }
                 tg_live |= 1ull << hl;
+                if (tg_flush_after) { tg_flush_after = false; flush_tags(); }
             }
             const double s0 = group8_sum(w0);
             const double s1 = group8_sum(w1);
@@ -374,29 +406,7 @@ void hop_lds64_kernel(HopParams p)
         // ---- flush the chunk: clock, trace, barrier diagnostics ----------------------
         const int done = hl;                // hops of this chunk that executed
         hist_v += hist_c; hist_c = 0;
-        if (!presim && tg_root) {
-            // ---- move the chunk's tags: memory still holds the state before the chunk --------
-            int4 tg_val = make_int4(0, 0, 0, 0);
-            if ((tg_root >> lane) & 1ull) tg_val = tags_g[tg_vac];
-            const bool is_live = (tg_live >> lane) & 1ull;
-            const int site_l = is_live ? tg_site : -1;
-            // a root's home site is vacant now unless a live atom sits on it
-            unsigned long long vac = 0ull;
-            for (unsigned long long rm = tg_root; rm; rm &= rm - 1ull) {
-                const int rl = __ffsll((long long)rm) - 1;
-                const int home = __builtin_amdgcn_readlane(tg_vac, rl);
-                if (ballot64(site_l == home) == 0ull) vac |= 1ull << rl;
-            }
-            const int src = (tg_ow & 63) << 2;
-            int4 tv;
-            tv.x = __builtin_amdgcn_ds_bpermute(src, tg_val.x);
-            tv.y = __builtin_amdgcn_ds_bpermute(src, tg_val.y);
-            tv.z = __builtin_amdgcn_ds_bpermute(src, tg_val.z) + (((tg_ow >> 8) & 255) - 64);
-            tv.w = __builtin_amdgcn_ds_bpermute(src, tg_val.w) + (((tg_ow >> 16) & 255) - 64);
-            if (is_live) tags_g[tg_site] = tv;
-            if ((vac >> lane) & 1ull) tags_g[tg_vac] = make_int4(-1, 0, 0, 0);
-            tg_live = 0ull; tg_root = 0ull; tg_site = -1;
-        }
+        flush_tags();
         if (!presim) {
             const double dt = lane < done ? (-1.0 / gam_v) * log(u_v) : 0.0;      // :530
             time_acc += wave_sum(dt);

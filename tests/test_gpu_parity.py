@@ -374,8 +374,10 @@ def test_selection_edges(kmc, tables, dense, nx, ny, which):
     rs = np.random.RandomState(0)
     occ = (rs.rand(3, nx, ny) < 0.5).astype(np.int8)
     occ[2] = 1                                           # full lattice: gamma == 0
+    occ[0, 0, 0] = 1                                     # entry 0 = site (0, 0) towards (1, 0): the first rho == 0 hop moves
+    occ[0, 1, 0] = 1                                     # an atom onto an occupied site, the next ones leave a vacant site
     draws = rs.rand(3, 40, 2)
-    draws[0, 10, 0] = 0.0
+    draws[0, [10, 21, 22, 35], 0] = 0.0                  # entry 0 whatever its rate, several times in one chunk
     draws[1, 25, 0] = 1.0
     with make_engine(kmc, tables, 3, nx, ny) as eng:
         eng.set_hop_kernel(which=which)
@@ -388,7 +390,7 @@ def test_selection_edges(kmc, tables, dense, nx, ny, which):
     rep = CO.Replica(occ[0], dense)
     rep.init_tags()
     done, ref_idx, _ = rep.run(draws[0], False)
-    assert done == 40 and ref_idx[10] == 0
+    assert done == 40 and (ref_idx[[10, 21, 22, 35]] == 0).all()
     assert np.array_equal(idx[0], ref_idx) and np.array_equal(lat[0], rep.occ)
     assert np.array_equal(tags[0], rep.tags) and np.array_equal(P[0], rep.P)
     rep1 = CO.Replica(occ[1], dense)
