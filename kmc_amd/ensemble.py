@@ -77,20 +77,25 @@ def finalize(acc, conc_points):
 
 
 def run_ensemble(engine_factory, nx, ny, conc_points, replicas_per_point, presim_steps, sim_steps,
-                 seed=0, window_mode='hex_ref', rank=0, world=1, device=0, table=None, reduce_device=None):
+                 seed=0, window_mode='hex_ref', rank=0, world=1, device=0, table=None, reduce_device=None,
+                 return_replicas=False):
     """The reference's ensemble loop for this rank's share of the replicas.
 
     engine_factory(R, nx, ny, window_mode, device) -> KMCEngine (so tests can
     inject one); ``table`` = ('base', vec512, dumbbell) or ('dense', array).
     One "step" = int(nx*ny*x) hops (hex_LiCoO2_kmc.py:484); replicas of different
     concentration take different hop counts per step (kmc_run_counts).
+    With ``return_replicas`` a third value holds THIS rank's per-replica numbers (conc, d_star, d_j,
+    hist, barrier statistics) for the per-iteration lines of LiCoO2_kmc.out (kmc_amd.report).
     """
     conc, point = shard_replicas(conc_points, replicas_per_point, rank, world)
     R = conc.size
     eng = engine_factory(R, nx, ny, window_mode, device)
     try:
         if table[0] == 'base':
-            eng.set_base_table(table[1], table[2])
+            from . import tables as _tables
+            eng.set_base_table(table[1], table[2] if len(table) > 2 and table[2] is not None
+                               else _tables.dumbbell_rate())
         else:
             eng.set_hex_table(table[1])
         eng.fill_random(conc, seed + 7919 * rank)
@@ -106,7 +111,11 @@ def run_ensemble(engine_factory, nx, ny, conc_points, replicas_per_point, presim
         sc = eng.scalars()
         acc = accumulate(point, len(conc_points), ds, dj, sc['time'], st['hops_done'].astype(np.float64),
                          sc['hist'].astype(np.float64))
+        local = dict(conc=conc, d_star=ds, d_j=dj, hist=sc['hist'], time=sc['time'],
+                     barrier=eng.barrier_stats()) if return_replicas else None
     finally:
         eng.close()
     acc = all_reduce_acc(acc, reduce_device)
+    if return_replicas:
+        return finalize(acc, conc_points), acc, local
     return finalize(acc, conc_points), acc

@@ -1,0 +1,142 @@
+"""The reference's driver loops on the GPU: the batched self-check drivers
+(kmc_amd.diagnostics, Mc_Lattice.py:243-302) and the sweep that writes the result files (kmc_amd.sweep,
+hex_LiCoO2_kmc.py:650-818), each replayed replica by replica with the C oracle on the same Philox
+lattices and draws.  Bar: integer observables exact, coefficients and clocks within 1e-12 relative."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle as CO          # noqa: E402
+from oracle import kmc_oracle as O         # noqa: E402
+from oracle import philox as PH            # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+RTOL = 1e-12
+A2 = (2.8334 * 10 ** (-8)) ** 2
+
+
+@pytest.fixture(scope='module')
+def base512():
+    return np.load(os.path.join(GOLDEN, 'tables.npz'))['base512_normcons']
+
+
+@pytest.fixture(scope='module')
+def dense(base512):
+    return O.build_hex_table(base512)
+
+
+def _replay(dense, fill_seed, run_seed, r, n, conc, pre_hops, sim_hops, mode):
+    """One replica as the engine defines it: Philox lattice, Philox draws, presim then sim."""
+    occ = PH.fill_lattice(fill_seed, r, n, n, conc)
+    d = PH.hop_draws(run_seed, r, 0, pre_hops + sim_hops)
+    rep = CO.Replica(occ, dense, mode)
+    if pre_hops:
+        done, _, _ = rep.run(d[:pre_hops], True)
+        assert done == pre_hops
+    rep.init_tags()
+    if sim_hops:
+        done, _, _ = rep.run(d[pre_hops:], False)
+        assert done == sim_hops
+    return rep
+
+
+def _class_coeffs(rep, n_li, n):
+    out = rep.diffusion(n_li / float(n * n))
+    return A2 * out[2] / (4 * rep.time.value * n_li), A2 * out[3] / (4 * rep.time.value * n_li)
+
+
+def test_dimension_check(base512, dense):
+    from kmc_amd import diagnostics as D
+    got = D.dimension_check(('base', base512), dimensions=[10, 23], averaging=3, presim_steps=3, sim_steps=5, seed=11)
+    assert sorted(got) == [10, 23]
+    for n in got:
+        n_li = int(0.2 * n * n)
+        for r in range(3):
+            rep = _replay(dense, 11 + n, 11 + n, r, n, 0.2, 3 * n_li, 5 * n_li, 'obj_ref')
+            np.testing.assert_allclose(got[n][r], _class_coeffs(rep, n_li, n)[1], rtol=RTOL)
+
+
+def test_HH_check(base512, dense):
+    from kmc_amd import diagnostics as D
+    got = D.HH_check(('base', base512), dimensions=[10, 20], averaging=4, steps=6, seed=3)
+    for n in got:
+        n_li = int(0.2 * n * n)
+        for r in range(4):
+            occ = PH.fill_lattice(3 + n, r, n, n, 0.2)
+            rep = CO.Replica(occ, dense, 'obj_ref')
+            rep.run(PH.hop_draws(3 + n, r, 0, 6 * n_li), True)
+            assert got[n][r] == rep.hist[1] / rep.hist[0]
+    # the check itself: the table is isotropic, so over many hops the ratio tends to 1 (Mc_Lattice.py:261)
+    # (loosely: hops come in back-and-forth pairs, so single lattices scatter by ~0.15)
+    long_run = D.HH_check(('base', base512), dimensions=[30], averaging=128, steps=300, seed=5)[30]
+    assert abs(long_run.mean() - 1) < 0.08
+
+
+def test_counts_check(base512, dense):
+    from kmc_amd import diagnostics as D
+    n, x, steps = 12, 0.2, 6
+    n_li = int(x * n * n)
+    curve = D.counts_check(('base', base512), dimension=n, concentration=x, steps=steps, stride=2, replicas=2, seed=8)
+    assert curve.shape == (3, 2)
+    for r in range(2):
+        for k in range(3):
+            rep = _replay(dense, 8, 8, r, n, x, 0, 2 * (k + 1) * n_li, 'obj_ref')
+            np.testing.assert_allclose(curve[k, r], _class_coeffs(rep, n_li, n)[1], rtol=RTOL)
+
+
+def test_concentration_run(base512, dense):
+    from kmc_amd import diagnostics as D
+    n, xs = 14, [0.90, 0.94]
+    got = D.concentration_run(('base', base512), n, concentrations=xs, averaging=3, presim_steps=2, sim_steps=3, seed=21)
+    for k, x in enumerate(xs):
+        n_li = int(x * n * n)
+        ds, dj = [], []
+        for a in range(3):
+            rep = _replay(dense, 21, 21, 3 * k + a, n, x, 2 * n_li, 3 * n_li, 'obj_ref')
+            s, j = _class_coeffs(rep, n_li, n)
+            ds.append(s)
+            dj.append(j)
+        assert got[k][0] == x
+        np.testing.assert_allclose(got[k][1:], [np.mean(dj), np.std(dj), np.mean(ds), np.std(ds)], rtol=1e-9)
+
+
+def test_sweep_writes_reference_files(base512, dense, tmp_path, capsys):
+    from kmc_amd import report, sweep
+    xs, avg, pre, sim, seed = [0.2, 0.5, 0.8], 3, 2, 3, 40
+    res = sweep.run_sweep(('base', base512, None), [10, 16], xs, avg, pre, sim, seed=seed, out_dir=str(tmp_path))
+    printed = capsys.readouterr().out
+    assert 'concentration is: 0.2' in printed and 'average barrier = ' in printed and 'max, min barrir = ' in printed
+    dat = report.read_data_out(str(tmp_path / 'LiCoO2_data.out'))
+    out = report.read_kmc_out(str(tmp_path / 'LiCoO2_kmc.out'))
+    assert out['size'] == [10, 10, 1] and out['presim'] == pre and out['sim'] == sim
+    row = 0
+    for n in (10, 16):
+        for k, x in enumerate(xs):
+            n_li = int(n * n * 1 * x)
+            ds, dj, tt, hist = [], [], [], np.zeros(6)
+            for a in range(avg):
+                r = k * avg + a                          # rank 0 of 1: replica index = point-major
+                rep = _replay(dense, seed + n, seed + n + 1, r, n, x, pre * n_li, sim * n_li, 'hex_ref')
+                o = rep.diffusion(x)
+                ds.append(o[0])
+                dj.append(o[1])
+                tt.append(rep.time.value)
+                hist += rep.hist
+            got = res[n][k]
+            assert got['concentration'] == x and got['replicas'] == avg
+            assert got['hop_histogram'] == hist.astype(np.int64).tolist()
+            np.testing.assert_allclose([got['d_star'], got['d_j'], got['time']], [np.mean(ds), np.mean(dj), np.mean(tt)],
+                                       rtol=RTOL)
+            np.testing.assert_allclose([got['error_star'], got['error_j']], [np.std(ds), np.std(dj)], rtol=1e-6)
+            # the files carry the same numbers
+            assert dat['Concentration'][row] == x and dat['Dimension'][row] == n
+            assert dat['D_star'][row] == got['d_star'] and dat['D_j'][row] == got['d_j'] and dat['time'][row] == got['time']
+            np.testing.assert_allclose(out['table'][row], [got['d_star'], x, got['error_star'], got['d_j'], got['error_j']],
+                                       rtol=2e-8)
+            row += 1
+    # per-iteration lines: the reader keys points by concentration, so the LAST dimension's lines survive
+    for k, x in enumerate(xs):
+        np.testing.assert_allclose(np.mean(out['points'][k][1]), res[16][k]['d_star'], rtol=2e-8)
