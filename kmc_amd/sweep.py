@@ -68,9 +68,28 @@ def run_sweep(table, dimensions, concentrations, averaging_iterations, presimula
     return all_results
 
 
+def temperature_sweep(kb_ts, dimensions, concentrations, averaging_iterations, presimulation_iterations=250,
+                      simulation_iterations=750, prefactor=tables.PREFACTOR, eci=tables.LCE_ECI, seed=0, out_dir='.',
+                      **kw):
+    """The sweep at several temperatures.  The reference's table "must be rerun for each temperature"
+    (hex_LiCoO2_kmc.py:345, minutes of Python per kT); here the 512 rates 1e13 exp(-E / kT) come from the device
+    generator (kmc_generate_base_table, :369-403 with :103-199) and the dumbbell rate from
+    hex_dict_builder.py:29-30 at the same kT.  Files go to ``out_dir/kbT_<kT>/``.  Returns {kT: run_sweep result}."""
+    out = {}
+    for kb_t in kb_ts:
+        with KMCEngine(1, 8, 8, 'hex_ref', kw.get('device', 0)) as eng:
+            base, _ = eng.generate_base_table(eci, prefactor, kb_t)
+        table = ('base', base, tables.dumbbell_rate(prefactor, kb_t))
+        out[kb_t] = run_sweep(table, dimensions, concentrations, averaging_iterations, presimulation_iterations,
+                              simulation_iterations, seed=seed, out_dir=os.path.join(out_dir, 'kbT_' + str(kb_t)),
+                              kb_t=kb_t, **kw)
+    return out
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
-    ap.add_argument('--table', required=True, help='normcons_dictionary.p / master_dictionary.p / hex_dict.p')
+    ap.add_argument('--table', help='normcons_dictionary.p / master_dictionary.p / hex_dict.p')
+    ap.add_argument('--kbt', type=float, nargs='+', help='instead of --table: generate the rates at these kT (eV)')
     ap.add_argument('--dimensions', type=int, nargs='+', default=[10])                      # :655
     ap.add_argument('--concentrations', type=float, nargs='+', default=[0.2])               # :659
     ap.add_argument('--averaging', type=int, default=8)
@@ -88,10 +107,16 @@ def main(argv=None):
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl')
         reduce_device = 'cuda:%d' % local_rank
-    kind, arr = tables.load_any(a.table)
-    table = ('base', arr, tables.dumbbell_rate()) if kind == 'base' else ('dense', arr)
-    run_sweep(table, a.dimensions, a.concentrations, a.averaging, a.presim, a.sim, a.seed, a.out_dir, rank, world,
-              local_rank, reduce_device)
+    if (a.table is None) == (a.kbt is None):
+        ap.error('give exactly one of --table and --kbt')
+    if a.kbt is not None:
+        temperature_sweep(a.kbt, a.dimensions, a.concentrations, a.averaging, a.presim, a.sim, seed=a.seed,
+                          out_dir=a.out_dir, rank=rank, world=world, device=local_rank, reduce_device=reduce_device)
+    else:
+        kind, arr = tables.load_any(a.table)
+        table = ('base', arr, tables.dumbbell_rate()) if kind == 'base' else ('dense', arr)
+        run_sweep(table, a.dimensions, a.concentrations, a.averaging, a.presim, a.sim, a.seed, a.out_dir, rank,
+                  world, local_rank, reduce_device)
     if world > 1:
         dist.destroy_process_group()
 

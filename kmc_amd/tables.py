@@ -115,3 +115,15 @@ def load_any(path):
     if len(d) >= 1 << 18:
         return 'dense', dense_from_hex_dict(d)
     return 'base', base512_from_dict(d)
+
+
+def write_hex_dict(path, dense, protocol=2):
+    """``hex_dict.p`` as hex_dict_builder.py:143-147 writes it: {18-char '0'/'1' key -> ndarray(6)}, 2^18
+    entries, for scripts that ``pickle.load`` it themselves (Mc_Lattice.py:64).  ``dense`` is the folded
+    table, e.g. ``KMCEngine.get_hex_table()``."""
+    t = np.ascontiguousarray(dense, dtype=np.float64)
+    if t.shape != (1 << 18, 6):
+        raise ValueError('dense table must be (262144, 6)')
+    d = {format(k, '018b'): t[k].copy() for k in range(1 << 18)}
+    with open(path, 'wb') as f:
+        pickle.dump(d, f, protocol)

@@ -140,3 +140,27 @@ def test_sweep_writes_reference_files(base512, dense, tmp_path, capsys):
     # per-iteration lines: the reader keys points by concentration, so the LAST dimension's lines survive
     for k, x in enumerate(xs):
         np.testing.assert_allclose(np.mean(out['points'][k][1]), res[16][k]['d_star'], rtol=2e-8)
+
+
+def test_temperature_sweep(tmp_path):
+    """Next row 2: rates regenerated per kT on the device, then the same sweep."""
+    from kmc_amd import report, sweep
+    kts, n, x, avg, pre, sim = [0.02, 0.035], 12, 0.4, 2, 2, 3
+    res = sweep.temperature_sweep(kts, [n], [x], avg, pre, sim, seed=7, out_dir=str(tmp_path), echo=False)
+    n_li = int(n * n * 1 * x)
+    d_by_t = []
+    for kt in kts:
+        base = O.generate_base512(10 ** 13, kt)
+        dense_t = O.build_hex_table(base, O.dumbbell_rate(10 ** 13, kt))
+        ds = []
+        for r in range(avg):
+            rep = _replay(dense_t, 7 + n, 7 + n + 1, r, n, x, pre * n_li, sim * n_li, 'hex_ref')
+            ds.append(rep.diffusion(x)[0])
+        got = res[kt][n][0]
+        # the device's exp may differ from libm's in the last place: selections are the same unless a draw falls
+        # within that of a boundary (never in a run this short), coefficients agree to the table's 1e-12
+        np.testing.assert_allclose(got['d_star'], np.mean(ds), rtol=1e-10)
+        out = report.read_kmc_out(str(tmp_path / ('kbT_' + str(kt)) / 'LiCoO2_kmc.out'))
+        assert out['kb_t'] == kt and out['size'] == [n, n, 1]
+        d_by_t.append(got['d_star'])
+    assert d_by_t[1] > d_by_t[0]                           # hotter lattice diffuses faster

@@ -101,3 +101,18 @@ def test_shard_and_statistics():
         np.testing.assert_allclose(out[p]['error_star'], np.std(ds[m]), rtol=1e-9)   # np.std, ddof 0 (:784)
         np.testing.assert_allclose(out[p]['error_j'], np.std(dj[m]), rtol=1e-9)
         assert out[p]['replicas'] == 64 and out[p]['hops'] == 6400
+
+
+def test_hex_dict_writer_round_trip(tmp_path):
+    """Next row 1: hex_dict.p for scripts that load it themselves; read back by the restricted loader."""
+    import os
+    from kmc_amd import tables
+    from oracle import kmc_oracle as O
+    base = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'tables.npz'))['base512_normcons']
+    dense = O.build_hex_table(base)
+    p = str(tmp_path / 'hex_dict.p')
+    tables.write_hex_dict(p, dense)
+    kind, arr = tables.load_any(p)
+    assert kind == 'dense' and np.array_equal(arr, dense)
+    d = tables.load_table_pickle(p)
+    assert len(d) == 1 << 18 and np.array_equal(d['111100110011001111'], dense[249039])
