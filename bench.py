@@ -162,6 +162,21 @@ def main():
                 traffic = tj['hbm_bytes_per_launch']         # measured with rocprofv3 --pmc, not live
         except OSError:
             pass
+        # what really bounds the kernel: vector-ALU issue.  VALU instructions per launch from the committed PMC
+        # pass (profiles/, SQ_INSTS_VALU, same command) / the live kernel time, against one wave64 VALU
+        # instruction per SIMD per 4 cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 4.
+        valu = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')) as f:
+                tj = json.load(f)
+            if tj.get('replicas') == R and tj.get('hops_per_launch') == hops_per_step and 'valu_insts_per_launch' in tj:
+                peak = 256 * 4 * 2.4e9 / 4
+                ach = tj['valu_insts_per_launch'] / (k_ms * 1e-3)
+                valu = {'achieved': ach / 1e9, 'peak': peak / 1e9, 'unit': 'G wave-instructions/s', 'frac': ach / peak,
+                        'insts_per_hop': tj['valu_insts_per_launch'] / (R * hops_per_step),
+                        'source': 'SQ_INSTS_VALU of profiles/%s_pmc.json (not live) / live kernel time' % tj.get('tag')}
+        except OSError:
+            pass
         out = {
             'metric': 'KMC hops/sec (whole node), 4096x64x64 hex replicas per GPU; D* match vs CPU ref',
             'value': value, 'unit': 'hops/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -175,6 +190,7 @@ def main():
                          'kernel': 'hop_q64_kernel', 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_hop': b_hop, 'hops_per_launch': R * hops_per_step,
                          'note': 'algorithmic bytes are those of the REFERENCE algorithm (full rate-matrix scan per hop); the kernel keeps replica state in LDS and scans hierarchically, so frac > 1 means traffic avoided, not HBM over peak'},
+            'valu_issue': valu,
             'kernel_hops_per_s': R * hops_per_step / (k_ms * 1e-3),
             'exact_path_hops': int(status['n_exact'].sum()), 'stopped_replicas': int((status['status'] != 0).sum()),
             'd_star_mean': stats['d_star'], 'd_star_std': stats['error_star'], 'd_j_mean': stats['d_j'],

@@ -37,6 +37,9 @@ if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
            'fetch_correction': 2.0, 'hbm_bytes_per_launch': int((2.0 * fetch_kb + write_kb) * 1024),
            'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py; '
                      'profiles/%s_pmc.json' % tag}
+    for k, name in (('SQ_INSTS_VALU', 'valu_insts_per_launch'), ('SQ_INSTS_SALU', 'salu_insts_per_launch')):
+        if k in c:
+            hbm[name] = c[k]['mean_per_launch']              # bench.py's valu_issue figure
     json.dump(hbm, open(os.path.join(dst, 'hbm_traffic.json'), 'w'), indent=1)
     out['hbm'] = hbm
 json.dump(out, open(os.path.join(dst, tag + '_pmc.json'), 'w'), indent=1)
