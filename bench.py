@@ -86,11 +86,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
     torch = None
+    backend = os.environ.get('KMC_BENCH_BACKEND', 'nccl')        # 'gloo': rehearsal of the N > 1 path on a 1-GPU box
+    red_dev = None
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            red_dev = torch.device('cuda', local_rank)
+            dist.init_process_group('nccl', device_id=red_dev)
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            dist.init_process_group(backend)
 
     import numpy as np
     import kmc_amd
@@ -120,7 +127,8 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if red_dev is not None:
+                torch.cuda.synchronize()
         eng.sync()
 
     barrier()
@@ -133,18 +141,24 @@ def main():
     st = eng.status()
     acc = ensemble.accumulate(np.zeros(R, dtype=np.int64), 1, ds, dj, sc['time'],
                               st['hops_done'].astype(np.float64), sc['hist'].astype(np.float64))
-    acc = ensemble.all_reduce_acc(acc, torch.device('cuda', local_rank) if torch is not None else None)
+    acc = ensemble.all_reduce_acc(acc, red_dev)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev if red_dev is not None else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     # duration of the dominant kernel: HIP events the engine recorded on its own
     # stream around each hop-kernel launch of the timed region
-    ev = eng.run_kernel_times(64)[-min(args.steps, 64):]
-    k_ms = float(np.mean(ev))
+    # A step may be several concurrent launches over disjoint replicas (kmc_set_launch_groups), and the launches
+    # of consecutive steps overlap, so the rate comes from the span: first kernel start of the timed region (of
+    # its last 64 steps) to last kernel end, divided by the steps in it.
+    n_span = min(args.steps, 64)
+    ev = eng.run_kernel_times(64)[-n_span:]
+    launch_ms = float(np.mean(ev))                           # one launch, as rocprofv3's kernel trace shows it
+    span_ms, groups = eng.run_span_ms(n_span)
+    k_ms = span_ms / n_span                                  # GPU time per step
     status = eng.status()
     stats = ensemble.finalize(acc, [CONC])[0]
 
@@ -153,13 +167,14 @@ def main():
         value = hops_total / elapsed
         b_hop = algorithmic_bytes_per_hop(N_SIDE)
         bytes_per_launch = b_hop * R * hops_per_step
-        achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+        achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9       # bytes_per_launch: of one step (all its launches)
         traffic = None
         try:
             with open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')) as f:
                 tj = json.load(f)
             if tj.get('replicas') == R and tj.get('hops_per_launch') == hops_per_step:
-                traffic = tj['hbm_bytes_per_launch']         # measured with rocprofv3 --pmc, not live
+                # measured with rocprofv3 --pmc, not live; per launch -> per step
+                traffic = int(tj['hbm_bytes_per_launch'] * (R / tj.get('replicas_per_launch', R)))
         except OSError:
             pass
         # what really bounds the kernel: vector-ALU issue.  VALU instructions per launch from the committed PMC
@@ -171,9 +186,10 @@ def main():
                 tj = json.load(f)
             if tj.get('replicas') == R and tj.get('hops_per_launch') == hops_per_step and 'valu_insts_per_launch' in tj:
                 peak = 256 * 4 * 2.4e9 / 4
-                ach = tj['valu_insts_per_launch'] / (k_ms * 1e-3)
+                per_step = tj['valu_insts_per_launch'] * (R / tj.get('replicas_per_launch', R))
+                ach = per_step / (k_ms * 1e-3)
                 valu = {'achieved': ach / 1e9, 'peak': peak / 1e9, 'unit': 'G wave-instructions/s', 'frac': ach / peak,
-                        'insts_per_hop': tj['valu_insts_per_launch'] / (R * hops_per_step),
+                        'insts_per_hop': per_step / (R * hops_per_step),
                         'source': 'SQ_INSTS_VALU of profiles/%s_pmc.json (not live) / live kernel time' % tj.get('tag')}
         except OSError:
             pass
@@ -187,8 +203,10 @@ def main():
                        'hops_per_step': hops_per_step, 'parallelism': 'replicas sharded over %d GPU(s), no data-path collective, one all-reduce of D* accumulators' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'hop_q64_kernel', 'kernel_ms': k_ms,
-                         'algorithmic_bytes_per_hop': b_hop, 'hops_per_launch': R * hops_per_step,
+                         'kernel': 'hop_q64_kernel', 'kernel_ms': k_ms, 'launches_per_step': groups,
+                         'launch_ms': launch_ms, 'algorithmic_bytes_per_hop': b_hop,
+                         'hops_per_launch': R * hops_per_step // groups,
+                         'span': 'a step is %d concurrent launch(es) over disjoint replicas and steps are not joined on the device; achieved and traffic are per step: the step\'s algorithmic bytes / kernel_ms, kernel_ms = HIP-event span of the timed launches / steps; launch_ms = mean duration of one launch (what rocprofv3 lists)' % groups,
                          'note': 'algorithmic bytes are those of the REFERENCE algorithm (full rate-matrix scan per hop); the kernel keeps replica state in LDS and scans hierarchically, so frac > 1 means traffic avoided, not HBM over peak'},
             'valu_issue': valu,
             'kernel_hops_per_s': R * hops_per_step / (k_ms * 1e-3),

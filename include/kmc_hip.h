@@ -56,6 +56,11 @@ int kmc_last_kernel_ms(kmc_ctx* ctx, float* ms);
  * kmc_run_counts, oldest first: HIP events recorded on the context's stream
  * around every launch.  Synchronises the stream. */
 int kmc_run_kernel_times(kmc_ctx* ctx, float* ms, int max_n, int* n_out);
+/* device time (ms, HIP events) from the start of the n_runs-th last run's first kernel to the end of the
+ * last run's last kernel, and in *groups_out (may be NULL) how many concurrent kernels the last run launched
+ * (see kmc_set_launch_groups); n_runs <= 64.  With launch groups kmc_run_kernel_times reports the first
+ * group's kernel of each run.  No counterpart in the reference. */
+int kmc_run_span_ms(kmc_ctx* ctx, int n_runs, float* span_ms, int* groups_out);
 
 /* ---- rate tables (row T) --------------------------------------------- */
 /* Folds a 512-entry base table into the 2^18 x 6 device table on the GPU:
@@ -162,6 +167,13 @@ int kmc_table_is_compact(kmc_ctx* ctx);
  * replicas 2 = the 8-replicas-per-CU kernel (kmc_hop_lds64.h), 3 = the 16-per-CU kernel (kmc_hop_q64.h);
  * the default is 3.  No counterpart in the reference. */
 int kmc_set_hop_kernel(kmc_ctx* ctx, int which);
+/* Launch groups of the 16-per-CU kernel.  mode 2: every run is launched as two kernels over the two halves of
+ * the replicas, each on a stream of its own, and consecutive runs are not joined (a group's next launch waits
+ * for that group's last one only), so one group's start-up, write-back and tail overlap the other's hop loop;
+ * every other entry point joins the groups first, results are those of one launch.  mode 1: one launch.
+ * mode 0 (default): two groups when the replicas exceed 3/4 of one resident round (3072).  No counterpart
+ * in the reference. */
+int kmc_set_launch_groups(kmc_ctx* ctx, int mode);
 /* profiling builds only (-DKMC_STAMPS): cycles [R][8] the last kmc_run spent per hop segment, measured
  * with s_memtime; any other build returns KMC_ESTATE.  No counterpart in the reference. */
 int kmc_debug_stamps(kmc_ctx* ctx, int64_t* out);

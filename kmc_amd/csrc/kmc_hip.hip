@@ -27,6 +27,7 @@ using namespace kmc;
 // ======================================================================
 // context
 // ======================================================================
+#define KMC_GROUPS 2
 struct kmc_ctx {
     int device, R, nx, ny, n, window_mode;
     bool lds_path;
@@ -40,7 +41,18 @@ struct kmc_ctx {
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     bool timed;
-    hipEvent_t run_ev[KMC_EV_RING][2];   // HIP events around the last hop-kernel launches
+    // A run of the 16-per-CU kernel over more replicas than ~3/4 of one resident round is launched as
+    // KMC_GROUPS kernels over disjoint replica ranges, each on a stream of its own.  Consecutive runs are NOT
+    // joined: group g's next launch waits for group g's last one only, so the groups drift apart and one's
+    // prologue / epilogue / tail overlaps the other's hop loop (+8 % at 4096 replicas, +35 % at 4608).  Every
+    // other entry point joins the groups into `stream` first (CTXCHK), the next run forks from it again.
+    hipStream_t gstream[KMC_GROUPS];
+    hipEvent_t gdone[KMC_GROUPS], fork_ev;
+    bool groups_busy, need_fork;
+    int timed_slot;                      // run_ev slot if the last timed launch was a run in groups, else -1
+    int split;                           // kmc_set_launch_groups: 0 = automatic, 1 = one launch, 2 = groups
+    hipEvent_t run_ev[KMC_EV_RING][KMC_GROUPS][2];   // HIP events around the last hop-kernel launches
+    unsigned char run_groups[KMC_EV_RING];
     long long run_launches;
     // device state
     uint8_t* occ;
@@ -90,13 +102,34 @@ static int fail(kmc_ctx* ctx, int code, const char* fmt, ...)
                         __FILE__, __LINE__);                                               \
     } while (0)
 
-#define CTXCHK(ctx)                                                    \
+// the launch groups of the last runs -> the context's stream (device-side: nothing blocks the host)
+static hipError_t join_groups(kmc_ctx* c)
+{
+    c->need_fork = true;
+    c->timed_slot = -1;                 // whoever joins is about to put work on the context's stream
+    if (!c->groups_busy) return hipSuccess;
+    for (int g = 0; g < KMC_GROUPS; ++g) {
+        hipError_t e = hipEventRecord(c->gdone[g], c->gstream[g]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->gdone[g], 0);
+        if (e != hipSuccess) return e;
+    }
+    c->groups_busy = false;
+    return hipSuccess;
+}
+
+#define CTXCHK_RUN(ctx)                                                \
     do {                                                               \
         if (!(ctx)) return fail(nullptr, KMC_EINVAL, "null context"); \
         HIPCHK(ctx, hipSetDevice((ctx)->device));                      \
     } while (0)
 
-static void time_begin(kmc_ctx* c) { hipEventRecord(c->ev0, c->stream); }
+#define CTXCHK(ctx)                                                    \
+    do {                                                               \
+        CTXCHK_RUN(ctx);                                               \
+        HIPCHK(ctx, join_groups(ctx));                                 \
+    } while (0)
+
+static void time_begin(kmc_ctx* c) { hipEventRecord(c->ev0, c->stream); c->timed_slot = -1; }
 static void time_end(kmc_ctx* c) { hipEventRecord(c->ev1, c->stream); c->timed = true; }
 
 // ======================================================================
@@ -466,7 +499,14 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CREATE_CHK(hipEventCreate(&c->ev0));
     CREATE_CHK(hipEventCreate(&c->ev1));
-    for (int k = 0; k < KMC_EV_RING; ++k) { CREATE_CHK(hipEventCreate(&c->run_ev[k][0])); CREATE_CHK(hipEventCreate(&c->run_ev[k][1])); }
+    for (int k = 0; k < KMC_EV_RING; ++k)
+        for (int g = 0; g < KMC_GROUPS; ++g) { CREATE_CHK(hipEventCreate(&c->run_ev[k][g][0])); CREATE_CHK(hipEventCreate(&c->run_ev[k][g][1])); }
+    for (int g = 0; g < KMC_GROUPS; ++g) {
+        CREATE_CHK(hipStreamCreateWithFlags(&c->gstream[g], hipStreamNonBlocking));
+        CREATE_CHK(hipEventCreateWithFlags(&c->gdone[g], hipEventDisableTiming));
+    }
+    CREATE_CHK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+    c->need_fork = true;
     const size_t Rn = (size_t)c->R * c->n;
     CREATE_CHK(hipMalloc((void**)&c->occ, Rn + 16));
     CREATE_CHK(hipMalloc((void**)&c->keys, Rn * 4 + 16));
@@ -533,13 +573,20 @@ int kmc_destroy(kmc_ctx* c)
 {
     if (!c) return KMC_OK;
     hipSetDevice(c->device);
+    for (int g = 0; g < KMC_GROUPS; ++g) if (c->gstream[g]) hipStreamSynchronize(c->gstream[g]);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* bufs[] = {c->occ, c->keys, c->tags, c->table, c->wsum, c->time_total, c->step_time, c->gamma, c->hist,
                     c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel, c->w_g, c->tcompact, c->tcompact2, c->hier, c->xscratch};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
-    for (int k = 0; k < KMC_EV_RING; ++k) for (int q = 0; q < 2; ++q) if (c->run_ev[k][q]) hipEventDestroy(c->run_ev[k][q]);
+    for (int k = 0; k < KMC_EV_RING; ++k) for (int g = 0; g < KMC_GROUPS; ++g) for (int q = 0; q < 2; ++q)
+        if (c->run_ev[k][g][q]) hipEventDestroy(c->run_ev[k][g][q]);
+    for (int g = 0; g < KMC_GROUPS; ++g) {
+        if (c->gdone[g]) hipEventDestroy(c->gdone[g]);
+        if (c->gstream[g]) hipStreamDestroy(c->gstream[g]);
+    }
+    if (c->fork_ev) hipEventDestroy(c->fork_ev);
     if (c->stream) hipStreamDestroy(c->stream);
     free(c);
     return KMC_OK;
@@ -559,6 +606,14 @@ int kmc_last_kernel_ms(kmc_ctx* c, float* ms)
     if (!c->timed) return fail(c, KMC_ESTATE, "kmc_last_kernel_ms: nothing timed yet");
     HIPCHK(c, hipEventSynchronize(c->ev1));
     HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    if (c->timed_slot >= 0) {                   // a run in launch groups: first start to last end
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int g = 1; g < c->run_groups[c->timed_slot]; ++g) {
+            float m2 = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&m2, c->ev0, c->run_ev[c->timed_slot][g][1]));
+            if (m2 > *ms) *ms = m2;
+        }
+    }
     return KMC_OK;
 }
 
@@ -571,9 +626,38 @@ int kmc_run_kernel_times(kmc_ctx* c, float* ms, int max_n, int* n_out)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (long long k = 0; k < n; ++k) {          // oldest first
         const int slot = (int)((c->run_launches - n + k) % KMC_EV_RING);
-        HIPCHK(c, hipEventElapsedTime(&ms[k], c->run_ev[slot][0], c->run_ev[slot][1]));
+        HIPCHK(c, hipEventElapsedTime(&ms[k], c->run_ev[slot][0][0], c->run_ev[slot][0][1]));
     }
     *n_out = (int)n;
+    return KMC_OK;
+}
+
+// GPU time from the start of the n-th last run's first kernel to the end of the last run's last kernel (HIP
+// events), and how many kernels each of those runs launched (1, or KMC_GROUPS concurrent ones).
+int kmc_run_span_ms(kmc_ctx* c, int n_runs, float* span_ms, int* groups_out)
+{
+    CTXCHK(c);
+    if (!span_ms || n_runs < 1 || n_runs > KMC_EV_RING || n_runs > c->run_launches)
+        return fail(c, KMC_EINVAL, "kmc_run_span_ms: need 1 <= n_runs <= min(%d, runs so far)", KMC_EV_RING);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int first = (int)((c->run_launches - n_runs) % KMC_EV_RING), last = (int)((c->run_launches - 1) % KMC_EV_RING);
+    float best = 0.f;
+    for (int gf = 0; gf < c->run_groups[first]; ++gf)
+        for (int gl = 0; gl < c->run_groups[last]; ++gl) {
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->run_ev[first][gf][0], c->run_ev[last][gl][1]));
+            if (ms > best) best = ms;
+        }
+    *span_ms = best;
+    if (groups_out) *groups_out = c->run_groups[last];
+    return KMC_OK;
+}
+
+int kmc_set_launch_groups(kmc_ctx* c, int mode)
+{
+    CTXCHK(c);
+    if (mode < 0 || mode > 2) return fail(c, KMC_EINVAL, "kmc_set_launch_groups: mode must be 0 (automatic), 1 or 2");
+    c->split = mode;
     return KMC_OK;
 }
 
@@ -928,12 +1012,13 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
 #endif
         const int slot = (int)(c->run_launches % KMC_EV_RING);
         time_begin(c);
-        HIPCHK(c, hipEventRecord(c->run_ev[slot][0], c->stream));
+        c->run_groups[slot] = 1;
+        HIPCHK(c, hipEventRecord(c->run_ev[slot][0][0], c->stream));
         if (c->have_compact)
             hop_big_kernel<true><<<c->R, KMC_BIG_THREADS, c->geom.lds_bytes, c->stream>>>(g);
         else
             hop_big_kernel<false><<<c->R, KMC_BIG_THREADS, c->geom.lds_bytes, c->stream>>>(g);
-        HIPCHK(c, hipEventRecord(c->run_ev[slot][1], c->stream));
+        HIPCHK(c, hipEventRecord(c->run_ev[slot][0][1], c->stream));
         time_end(c);
         ++c->run_launches;
         HIPCHK(c, hipGetLastError());
@@ -959,9 +1044,10 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         const size_t lds = ((sizeof(GbShared) + 15) & ~(size_t)15) + (size_t)c->nx * 8;
         const int slot = (int)(c->run_launches % KMC_EV_RING);
         time_begin(c);
-        HIPCHK(c, hipEventRecord(c->run_ev[slot][0], c->stream));
+        c->run_groups[slot] = 1;
+        HIPCHK(c, hipEventRecord(c->run_ev[slot][0][0], c->stream));
         hop_global_kernel<<<c->R, KMC_GB_THREADS, lds, c->stream>>>(g);
-        HIPCHK(c, hipEventRecord(c->run_ev[slot][1], c->stream));
+        HIPCHK(c, hipEventRecord(c->run_ev[slot][0][1], c->stream));
         time_end(c);
         ++c->run_launches;
         HIPCHK(c, hipGetLastError());
@@ -987,11 +1073,44 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     p.stamps = dcounts ? nullptr : reinterpret_cast<long long*>(c->scratch_d);
 #endif
     const int slot = (int)(c->run_launches % KMC_EV_RING);
-    time_begin(c);
-    HIPCHK(c, hipEventRecord(c->run_ev[slot][0], c->stream));
     p.tcompact = c->tcompact;
     p.xscratch = c->xscratch;
     p.tcompact2 = c->tcompact2;
+    // more than 12 replicas per CU (3 waves per SIMD) of the 16-per-CU kernel: two launch groups (see kmc_ctx)
+    const bool split = c->lds64 && c->q64 && c->R >= 2 * 8 && (c->split == 2 || (c->split == 0 && c->R > 3072));
+    if (split) {
+        if (c->need_fork) {
+            HIPCHK(c, hipEventRecord(c->fork_ev, c->stream));
+            for (int g = 0; g < KMC_GROUPS; ++g) HIPCHK(c, hipStreamWaitEvent(c->gstream[g], c->fork_ev, 0));
+            c->need_fork = false;
+        }
+        const int r_half = ((c->R / 2 + 7) / 8) * 8;         // multiples of 8: blocks go round the 8 XCDs
+        c->run_groups[slot] = KMC_GROUPS;
+        for (int g = 0; g < KMC_GROUPS; ++g) {
+            p.r_base = g == 0 ? 0 : r_half;
+            const int rg = g == 0 ? r_half : c->R - r_half;
+            if (g == 0) hipEventRecord(c->ev0, c->gstream[0]);
+            HIPCHK(c, hipEventRecord(c->run_ev[slot][g][0], c->gstream[g]));
+            if (c->have_compact)
+                hop_q64_kernel<true><<<rg, 64, Q64_LDS_BYTES, c->gstream[g]>>>(p);
+            else
+                hop_q64_kernel<false><<<rg, 64, Q64_LDS_BYTES, c->gstream[g]>>>(p);
+            HIPCHK(c, hipEventRecord(c->run_ev[slot][g][1], c->gstream[g]));
+            if (g == 0) { hipEventRecord(c->ev1, c->gstream[0]); c->timed = true; c->timed_slot = slot; }
+        }
+        c->groups_busy = true;
+        ++c->run_launches;
+        HIPCHK(c, hipGetLastError());
+        if (sel_out || draws) {
+            HIPCHK(c, join_groups(c));
+            if (sel_out) HIPCHK(c, hipMemcpyAsync(sel_out, c->sel, Rh * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        return KMC_OK;
+    }
+    c->run_groups[slot] = 1;
+    time_begin(c);
+    HIPCHK(c, hipEventRecord(c->run_ev[slot][0][0], c->stream));
 #ifdef Q64_FORCE_DENSE          // scripts/variants.py: A/B of the pair tables against the dense table
     if (false)
 #else
@@ -1006,7 +1125,7 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         hop_lds64_kernel<false><<<c->R, 64, K64_LDS_BYTES, c->stream>>>(p);
     else
         hop_lds_kernel<<<c->R, 64, host_hop_lds_bytes(c->nx, c->n), c->stream>>>(p);
-    HIPCHK(c, hipEventRecord(c->run_ev[slot][1], c->stream));
+    HIPCHK(c, hipEventRecord(c->run_ev[slot][0][1], c->stream));
     time_end(c);
     ++c->run_launches;
     HIPCHK(c, hipGetLastError());
@@ -1033,7 +1152,8 @@ int kmc_debug_stamps(kmc_ctx* c, int64_t* out)
 
 int kmc_run(kmc_ctx* c, int64_t n_hops, int presim, const double* draws, uint64_t seed, int32_t* sel_out)
 {
-    CTXCHK(c);
+    CTXCHK_RUN(c);
+    if (draws || sel_out) HIPCHK(c, join_groups(c));         // staging copies go through the context's stream
     return run_impl(c, n_hops, nullptr, presim, draws, seed, sel_out);
 }
 

@@ -66,6 +66,7 @@ struct HopParams {
     long long* stamps;           // [R][8] cycles per segment (-DKMC_STAMPS profiling builds only) or null
     void* xscratch;              // [R][Q64_XSCRATCH] exact-path scratch of hop_q64_kernel
     const double* tcompact2;     // [3][2^15][2] pair tables (hop_q64_kernel<true>) or null
+    int r_base;                  // hop_q64_kernel: replica of block 0 (a run may be launched as several groups)
 };
 
 // Profiling builds (-DKMC_STAMPS, scripts/stamps.py) time the segments of a hop with s_memtime.

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Q64_WAVES_PE
 void hop_q64_kernel(HopParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int r = blockIdx.x, lane = threadIdx.x;
+    const int r = blockIdx.x + p.r_base, lane = threadIdx.x;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     uint16_t* klo = reinterpret_cast<uint16_t*>(smem + Q64_KLO);
     uint32_t* khp = reinterpret_cast<uint32_t*>(smem + Q64_KHP);

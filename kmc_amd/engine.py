@@ -81,6 +81,16 @@ class KMCEngine:
         self._chk(self._lib.kmc_run_kernel_times(self._ctx, buf, max_n, C.byref(n)))
         return [buf[k] for k in range(n.value)]
 
+    def run_span_ms(self, n_runs):
+        """(ms from the first kernel start of the n_runs-th last run to the last kernel end, kernels per run)."""
+        ms, g = C.c_float(), C.c_int()
+        self._chk(self._lib.kmc_run_span_ms(self._ctx, int(n_runs), C.byref(ms), C.byref(g)))
+        return ms.value, g.value
+
+    def set_launch_groups(self, mode):
+        """0 automatic, 1 one launch per run, 2 two concurrent launch groups (include/kmc_hip.h)."""
+        self._chk(self._lib.kmc_set_launch_groups(self._ctx, int(mode)))
+
     @property
     def uses_lds_path(self):
         return bool(self._lib.kmc_uses_lds_path(self._ctx))

@@ -583,3 +583,38 @@ def test_full_size_ensemble_two_kernels(kmc, tables):
     np.testing.assert_allclose(a[7], b[7], rtol=1e-13)
     # conservation: hops move atoms, they never create or destroy them
     assert np.array_equal(a[0].reshape(R, -1).sum(axis=1), (a[2].reshape(R, -1, 4)[:, :, 0] >= 0).sum(axis=1))
+
+
+# ---------------------------------------------------------------- launch groups
+def test_launch_groups_equal_one_launch(kmc, tables):
+    """kmc_set_launch_groups: a run launched as two kernels over the two halves of the replicas, runs not
+    joined in between, is the same computation replica by replica -- every output bit-identical to one launch
+    per run; injected draws, traces, per-replica hop counts and the free-running Philox sequence."""
+    R, seed = 77, 0xABCDEF                                   # odd: unequal halves (40 + 37)
+    conc = np.tile(np.linspace(0.1, 0.9, 9), R // 9 + 1)[:R]
+    rs = np.random.RandomState(5)
+    d_inj = rs.rand(R, 150, 2)
+    counts = rs.randint(0, 3000, size=R)
+    out = []
+    for mode in (1, 2):
+        with make_engine(kmc, tables, R, 64, 64) as eng:
+            eng.set_launch_groups(mode)
+            eng.fill_random(conc, 17)
+            eng.rates_full()
+            eng.run(1000, presim=True, seed=seed)
+            eng.init_displacements()
+            for _ in range(5):                               # back to back: the groups run free
+                eng.run(700, presim=False, seed=seed)
+            t1 = eng.run(150, presim=False, draws=d_inj, want_trace=True)
+            eng.run_counts(counts, presim=False, seed=seed)
+            eng.run(333, presim=False, seed=seed)
+            t2 = eng.run(64, presim=False, seed=seed, want_trace=True)
+            ms, groups = eng.run_span_ms(3)
+            assert groups == mode and ms > 0
+            sc, st = eng.scalars(), eng.status()
+            ds, dj, _ = eng.diffusion(conc)
+            out.append((eng.get_lattice(), eng.get_keys(), eng.get_displacements(), sc['hist'], st['hops_done'],
+                        st['status'], st['n_exact'], sc['time'], sc['gamma'], t1, t2, ds, dj, eng.barrier_stats()['sum']))
+    for k, (a, b) in enumerate(zip(*out)):
+        assert np.array_equal(a, b), k
+    assert (out[0][4] == 1000 + 3500 + 150 + counts + 333 + 64).all() and not out[0][5].any()
