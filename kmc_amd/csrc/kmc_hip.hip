@@ -608,11 +608,14 @@ int kmc_last_kernel_ms(kmc_ctx* c, float* ms)
     HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
     if (c->timed_slot >= 0) {                   // a run in launch groups: first start to last end
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (int g = 1; g < c->run_groups[c->timed_slot]; ++g) {
-            float m2 = 0.f;
-            HIPCHK(c, hipEventElapsedTime(&m2, c->ev0, c->run_ev[c->timed_slot][g][1]));
-            if (m2 > *ms) *ms = m2;
-        }
+        // (either group may get the chip first: take the earliest start against the latest end)
+        const int sl = c->timed_slot;
+        for (int gf = 0; gf < c->run_groups[sl]; ++gf)
+            for (int gl = 0; gl < c->run_groups[sl]; ++gl) {
+                float m2 = 0.f;
+                HIPCHK(c, hipEventElapsedTime(&m2, c->run_ev[sl][gf][0], c->run_ev[sl][gl][1]));
+                if (m2 > *ms) *ms = m2;
+            }
     }
     return KMC_OK;
 }

@@ -70,12 +70,34 @@ struct HopParams {
 };
 
 // Profiling builds (-DKMC_STAMPS, scripts/stamps.py) time the segments of a hop with s_memtime.
-#ifdef KMC_STAMPS
+// -DKMC_STAMPS=2 (hop_q64_kernel): no stamps inside the loop, only each wave's shader-clock and real-time
+// (100 MHz) counters at its start and end: the clock the chip held and when each wave of a launch ended.
+#if defined(KMC_STAMPS) && KMC_STAMPS != 2
 #define KMC_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
                           st_acc[k] += now_ - st_last; st_last = now_; } while (0)
 #else
 #define KMC_STAMP(k) do {} while (0)
 #endif
+
+// The SIMD's arbiter serves its oldest wave first: left alone, the waves of a SIMD finish one after the other
+// (hop_q64_kernel: 2.9 ... 4.4 ms for the same 2048 hops, scripts/wave_clocks.py) and a launch waits for the
+// last one, which ends up alone on its SIMD.  With priorities that rotate, a new one every 64-hop chunk, they
+// advance together: -12 % per launch at four waves per SIMD.
+__device__ __forceinline__ int kmc_wave_slot()
+{
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hwid));          // WAVE_ID: slot on the SIMD
+    return (int)hwid;
+}
+__device__ __forceinline__ void kmc_rotate_priority(int k)
+{
+    switch (k & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
 
 // The workgroup is ONE wave: its LDS instructions execute in issue order, so a
 // cross-lane LDS hand-off needs no s_barrier and no s_waitcnt, only a point the
@@ -202,8 +224,10 @@ __global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
+    const int wave_slot = kmc_wave_slot();
     for (long long h0 = 0; h0 < my_hops && status == 0; h0 += KMC_WAVE) {
         const int cnt = (int)((my_hops - h0) < KMC_WAVE ? (my_hops - h0) : KMC_WAVE);
+        kmc_rotate_priority((int)(h0 >> 6) + wave_slot);       // the waves of a SIMD advance together (kmc_hop_lds.h)
         // ---- uniforms for the next 64 hops, one hop per lane --------------
         double rho_v = 0.5, u_v = 1.0;
         if (lane < cnt) {

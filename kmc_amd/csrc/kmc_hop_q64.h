@@ -123,6 +123,9 @@ void hop_q64_kernel(HopParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int r = blockIdx.x + p.r_base, lane = threadIdx.x;
+#if defined(KMC_STAMPS) && KMC_STAMPS == 2
+    const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     uint16_t* klo = reinterpret_cast<uint16_t*>(smem + Q64_KLO);
     uint32_t* khp = reinterpret_cast<uint32_t*>(smem + Q64_KHP);
@@ -252,8 +255,14 @@ void hop_q64_kernel(HopParams p)
     // (+75 vector instructions per hop); up here hardly anything is live.
     bool need_exact = false;
     int done = 0;
+    const int wave_slot = kmc_wave_slot();
     for (long long h0 = 0; h0 < my_hops && status == 0; h0 += done) {
         const int cnt = (int)((my_hops - h0) < KMC_WAVE ? (my_hops - h0) : KMC_WAVE);
+        // The SIMD's arbiter serves its oldest wave first: left alone, the four waves of a SIMD finish one after the
+        // other (2.9 ... 4.4 ms for the same 2048 hops, scripts/wave_clocks.py), and the launch waits for the last
+        // one, which ends up alone on its SIMD.  With priorities that rotate, a new one every chunk, the four
+        // advance together (3.5 ... 3.9 ms): -12 % per launch.  (Rotating every 16, 4 or 1 hops is no better.)
+        kmc_rotate_priority((int)(h0 >> 6) + wave_slot);
         // ---- uniforms for the next 64 hops, one hop per lane --------------
         // (the clock's draw u is needed only at the flush and is produced again there: two registers
         // fewer across the hop loop, which runs at the 128-register limit of 4 waves per SIMD)
@@ -627,6 +636,19 @@ void hop_q64_kernel(HopParams p)
         QP->hops_done[r] = hop0 + hops;
         QP->n_exact[r] += n_exact;
         QP->status[r] |= status;
+#if defined(KMC_STAMPS) && KMC_STAMPS == 2
+        st_acc[0] = __builtin_amdgcn_s_memtime() - ck_t0;
+        st_acc[3] = __builtin_amdgcn_s_memrealtime();
+        st_acc[1] = st_acc[3] - ck_rt0;
+        st_acc[2] = ck_rt0;
+        {
+            unsigned hwid;                                   // HW_ID: wave, SIMD, CU, SH, SE, ... (which slot ran it)
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            st_acc[4] = hwid; st_acc[5] = xcc;
+        }
+#endif
 #ifdef KMC_STAMPS
         if (QP->stamps)
             for (int k = 0; k < 8; ++k) QP->stamps[r * 8 + k] = (long long)st_acc[k];
