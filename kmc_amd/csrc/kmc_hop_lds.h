@@ -82,7 +82,10 @@ struct HopParams {
 // The SIMD's arbiter serves its oldest wave first: left alone, the waves of a SIMD finish one after the other
 // (hop_q64_kernel: 2.9 ... 4.4 ms for the same 2048 hops, scripts/wave_clocks.py) and a launch waits for the
 // last one, which ends up alone on its SIMD.  With priorities that rotate, a new one every 64-hop chunk, they
-// advance together: -12 % per launch at four waves per SIMD.
+// advance together (3.5 ... 3.85 ms): -12 % per launch at four waves per SIMD.  The priority is
+// (slot on the SIMD - chunks done) mod 4: distinct for waves in step, and a wave that gets a chunk ahead drops
+// below its neighbours (rotating the other way, + chunks done, is 3 % slower on long launches; cycling through
+// all 24 orders of the four priorities or rotating every 16, 4 or 1 hops is no better).
 __device__ __forceinline__ int kmc_wave_slot()
 {
     unsigned hwid;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
     const int wave_slot = kmc_wave_slot();
     for (long long h0 = 0; h0 < my_hops && status == 0; h0 += KMC_WAVE) {
         const int cnt = (int)((my_hops - h0) < KMC_WAVE ? (my_hops - h0) : KMC_WAVE);
-        kmc_rotate_priority((int)(h0 >> 6) + wave_slot);       // the waves of a SIMD advance together (kmc_hop_lds.h)
+        kmc_rotate_priority(wave_slot - (int)(h0 >> 6));       // the waves of a SIMD advance together (kmc_hop_lds.h)
         // ---- uniforms for the next 64 hops, one hop per lane --------------
         double rho_v = 0.5, u_v = 1.0;
         if (lane < cnt) {

@@ -212,7 +212,7 @@ void hop_lds64_kernel(HopParams p)
     const int wave_slot = kmc_wave_slot();
     for (long long h0 = 0; h0 < my_hops && status == 0; h0 += KMC_WAVE) {
         const int cnt = (int)((my_hops - h0) < KMC_WAVE ? (my_hops - h0) : KMC_WAVE);
-        kmc_rotate_priority((int)(h0 >> 6) + wave_slot);       // the waves of a SIMD advance together (kmc_hop_lds.h)
+        kmc_rotate_priority(wave_slot - (int)(h0 >> 6));       // the waves of a SIMD advance together (kmc_hop_lds.h)
         // ---- uniforms for the next 64 hops, one hop per lane --------------
         double rho_v = 0.5, u_v = 1.0;
         if (lane < cnt) {

@@ -258,11 +258,8 @@ void hop_q64_kernel(HopParams p)
     const int wave_slot = kmc_wave_slot();
     for (long long h0 = 0; h0 < my_hops && status == 0; h0 += done) {
         const int cnt = (int)((my_hops - h0) < KMC_WAVE ? (my_hops - h0) : KMC_WAVE);
-        // The SIMD's arbiter serves its oldest wave first: left alone, the four waves of a SIMD finish one after the
-        // other (2.9 ... 4.4 ms for the same 2048 hops, scripts/wave_clocks.py), and the launch waits for the last
-        // one, which ends up alone on its SIMD.  With priorities that rotate, a new one every chunk, the four
-        // advance together (3.5 ... 3.9 ms): -12 % per launch.  (Rotating every 16, 4 or 1 hops is no better.)
-        kmc_rotate_priority((int)(h0 >> 6) + wave_slot);
+        // priority = (slot on the SIMD - chunks done) mod 4: see kmc_rotate_priority (kmc_hop_lds.h)
+        kmc_rotate_priority(wave_slot - (int)(h0 >> 6));
         // ---- uniforms for the next 64 hops, one hop per lane --------------
         // (the clock's draw u is needed only at the flush and is produced again there: two registers
         // fewer across the hop loop, which runs at the 128-register limit of 4 waves per SIMD)

@@ -8,9 +8,7 @@ if '--build' in sys.argv:
     out = os.path.join(ROOT, 'kmc_amd', 'libkmc_hip_clocks.so')
     subprocess.check_call([build.hipcc()] + build.FLAGS + ['-DKMC_STAMPS=2', '-o', out, build.SRC])
     print(out)
-    out = os.path.join(ROOT, 'kmc_amd', 'libkmc_hip_clocks_prio.so')
-    subprocess.check_call([build.hipcc()] + build.FLAGS + ['-DKMC_STAMPS=2', '-DQ64_PRIO', '-o', out, build.SRC])
-    print(out); sys.exit(0)
+    sys.exit(0)
 import ctypes as C
 import numpy as np
 import kmc_amd
@@ -44,6 +42,14 @@ for mode in (1, 2):
     print('   waves per CU: min %d max %d over %d CUs;  per SIMD: min %d max %d;  duration by waves on the SIMD: %s'
           % (per_cu[per_cu > 0].min(), per_cu.max(), (per_cu > 0).sum(), per_simd[per_simd > 0].min(), per_simd.max(),
              {int(k): round(float(dur[per_simd[slot * 4 + simd] == k].mean())) for k in np.unique(per_simd[per_simd > 0])}), flush=True)
+    wid = hw & 15
+    key = slot * 4 + simd
+    distinct = sum(len(set((wid[key == k] & 3).tolist())) == 4 for k in np.unique(key))
+    print('   SIMDs whose 4 waves have 4 different (WAVE_ID & 3): %d of %d;  duration by WAVE_ID: %s' % (
+        distinct, len(np.unique(key)), {int(w): round(float(dur[wid == w].mean())) for w in np.unique(wid)}), flush=True)
+    spread = [dur[key == k].max() - dur[key == k].min() for k in np.unique(key)]
+    print('   spread (max - min duration) inside a SIMD: mean %.0f us;  between SIMD means: std %.0f us;  between CU means: std %.0f us'
+          % (np.mean(spread), np.std([dur[key == k].mean() for k in np.unique(key)]), np.std([dur[slot == k].mean() for k in np.unique(slot)])), flush=True)
     for x in range(8):
         m = xcc == x
         if m.any():
