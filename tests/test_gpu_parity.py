@@ -618,3 +618,22 @@ def test_launch_groups_equal_one_launch(kmc, tables):
     for k, (a, b) in enumerate(zip(*out)):
         assert np.array_equal(a, b), k
     assert (out[0][4] == 1000 + 3500 + 150 + counts + 333 + 64).all() and not out[0][5].any()
+
+
+def test_launch_group_controls_reject_bad_arguments(kmc, tables):
+    with make_engine(kmc, tables, 16, 64, 64) as eng:
+        with pytest.raises(kmc.engine.KMCError):
+            eng.set_launch_groups(3)
+        with pytest.raises(kmc.engine.KMCError):
+            eng.run_span_ms(1)                              # nothing has run yet
+        eng.fill_random(0.5, 1)
+        eng.rates_full()
+        eng.set_launch_groups(2)
+        eng.run(10, presim=True, seed=1)
+        ms, groups = eng.run_span_ms(1)
+        assert groups == 2 and ms > 0 and eng.last_kernel_ms() >= ms * 0.999
+        with pytest.raises(kmc.engine.KMCError):
+            eng.run_span_ms(2)                              # more runs than there were
+        with pytest.raises(kmc.engine.KMCError):
+            eng.run_span_ms(65)
+        assert (eng.status()['hops_done'] == 10).all()
