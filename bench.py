@@ -122,6 +122,7 @@ def main():
     for _ in range(args.warmup):
         eng.run(hops_per_step, presim=False, seed=seed + rank)
     eng.diffusion(CONC)              # warm-up of the exchange step too (first call loads its kernel)
+    ensemble.all_reduce_acc(np.zeros((1, len(ensemble.ACC_FIELDS))), red_dev)   # ... and of the collective (RCCL set-up)
     eng.sync()
 
     def barrier():
