@@ -247,6 +247,9 @@ void hop_q64_kernel(HopParams p)
 #ifdef KMC_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#if KMC_STAMPS == 2
+    st_acc[6] = __builtin_amdgcn_s_memrealtime() - ck_rt0;            // the prologue (100 MHz ticks)
+#endif
 #endif
     // Hops run in chunks of up to 64 (one hop's draws per lane).  A hop that cannot be certified ENDS its
     // chunk early: the chunk is flushed with the hops done so far and the next chunk starts with that hop,
@@ -616,6 +619,9 @@ void hop_q64_kernel(HopParams p)
     }
     // ---- store the replica --------------------------------------------------------------
     wave_fence();
+#if defined(KMC_STAMPS) && KMC_STAMPS == 2
+    st_acc[7] = __builtin_amdgcn_s_memrealtime();                     // the write-back starts
+#endif
     uint8_t* occ_g = Q64_OCC_G;
     uint32_t* keys_g = Q64_KEYS_G;
     for (int i = 0; i < 64; ++i) occ_g[i * 64 + lane] = (uint8_t)((cb >> i) & 1ull);
@@ -635,7 +641,9 @@ void hop_q64_kernel(HopParams p)
         QP->status[r] |= status;
 #if defined(KMC_STAMPS) && KMC_STAMPS == 2
         st_acc[0] = __builtin_amdgcn_s_memtime() - ck_t0;
+        __builtin_amdgcn_s_waitcnt(0);                                 // the stores of the write-back have left
         st_acc[3] = __builtin_amdgcn_s_memrealtime();
+        st_acc[7] = st_acc[3] - st_acc[7];
         st_acc[1] = st_acc[3] - ck_rt0;
         st_acc[2] = ck_rt0;
         {

@@ -34,6 +34,8 @@ for mode in (1, 2):
           'p5 %.0f, p50 %.0f, p95 %.0f, max %.0f;  starts within %.0f us;  ends: p5 %.0f p50 %.0f p95 %.0f max %.0f us'
           % (g, span / 8, clk.mean(), clk.min(), clk.max(), dur.mean(), *np.percentile(dur, [5, 50, 95]), dur.max(),
              t0.max(), *np.percentile(t1, [5, 50, 95]), t1.max()), flush=True)
+    print('   prologue (state into LDS, sums): %.0f us mean, max %.0f;  write-back: %.0f us mean, max %.0f'
+          % (st[:, 6].mean() / 100.0, st[:, 6].max() / 100.0, st[:, 7].mean() / 100.0, st[:, 7].max() / 100.0), flush=True)
     hw = st[:, 4]
     simd, cu, sh, se, xcc = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7, st[:, 5] & 15
     slot = ((xcc * 8 + se) * 2 + sh) * 16 + cu
