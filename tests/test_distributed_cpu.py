@@ -58,3 +58,72 @@ def test_two_rank_all_reduce(tmp_path):
         assert res['fin'][p]['replicas'] == 8
         np.testing.assert_allclose(res['fin'][p]['d_star'], np.mean(all_ds[p]), rtol=1e-13)
         np.testing.assert_allclose(res['fin'][p]['error_star'], np.std(all_ds[p]), rtol=1e-9)
+
+
+SWEEP_WORKER = textwrap.dedent('''
+    import os, sys, json
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch.distributed as dist
+    from kmc_amd import sweep
+
+    class FakeEngine:
+        """Stands in for the device: deterministic numbers from (fill seed, replica, concentration)."""
+        def __init__(self, R, nx, ny, wm, dev):
+            self.R, self.n, self.hops = R, nx * ny, np.zeros(R, dtype=np.int64)
+        def set_base_table(self, base, dumbbell): pass
+        def fill_random(self, conc, seed): self.conc, self.seed = np.asarray(conc, dtype=float), seed
+        def rates_full(self): pass
+        def init_displacements(self): pass
+        def run_counts(self, n, presim=False, seed=0): self.hops += np.asarray(n)
+        def status(self): return dict(status=np.zeros(self.R, dtype=np.int32), hops_done=self.hops, n_exact=self.hops * 0)
+        def _v(self): return (1 + np.arange(self.R)) * self.conc * (1 + (self.seed %% 97))
+        def diffusion(self, conc): return self._v() * 1e-10, self._v() * 3e-10, np.zeros((self.R, 4))
+        def scalars(self): return dict(time=self._v() * 1e-6, hist=np.tile(np.arange(6), (self.R, 1)) + self.hops[:, None])
+        def barrier_stats(self): return dict(sum=self._v(), count=np.ones(self.R), min=self._v() * 0.5, max=self._v() * 2, last=self._v())
+        def close(self): pass
+
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    res = sweep.run_sweep(('base', np.ones(512), 1.0), [8, 12], [0.25, 0.5], 4, 2, 3, seed=5, out_dir=sys.argv[1],
+                          rank=rank, world=world, engine_factory=FakeEngine, echo=False)
+    if rank == 0:
+        print('RESULT ' + json.dumps({str(k): v for k, v in res.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+''') % ROOT
+
+
+def test_two_rank_sweep_writes_files(tmp_path):
+    """The driver script's loop (kmc_amd.sweep) over two gloo ranks with a stand-in engine: every rank takes half
+    of each concentration's replicas, the means are over both, rank 0 writes the reference's result files."""
+    import json
+    from kmc_amd import report
+    script = tmp_path / 'sweep_worker.py'
+    script.write_text(SWEEP_WORKER)
+    out_dir = tmp_path / 'out'
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+           '--master-addr', '127.0.0.1', '--master-port', '29619', str(script), str(out_dir)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('RESULT ')][0][7:])
+    dat = report.read_data_out(str(out_dir / 'LiCoO2_data.out'))
+    kout = report.read_kmc_out(str(out_dir / 'LiCoO2_kmc.out'))
+    assert kout['size'] == [8, 8, 1] and kout['presim'] == 2 and kout['sim'] == 3
+    row = 0
+    for n in (8, 12):
+        for k, x in enumerate((0.25, 0.5)):
+            # what the stand-in engines of both ranks produce for this point: 2 local replicas each
+            vals = []
+            for rank in range(2):
+                fill_seed = 5 + n + 7919 * rank
+                local_index = 2 * k + np.arange(2)                   # point-major within the rank
+                vals += ((1 + local_index) * x * (1 + fill_seed % 97)).tolist()
+            r = res[str(n)][k]
+            assert r['replicas'] == 4 and r['hops'] == 4 * 5 * int(n * n * x)
+            np.testing.assert_allclose(r['d_star'], np.mean(vals) * 1e-10, rtol=1e-13)
+            np.testing.assert_allclose(r['error_j'], np.std(vals) * 3e-10, rtol=1e-8)
+            assert dat['Dimension'][row] == n and dat['Concentration'][row] == x and dat['D_star'][row] == r['d_star']
+            np.testing.assert_allclose(kout['table'][row], [r['d_star'], x, r['error_star'], r['d_j'], r['error_j']], rtol=2e-8)
+            row += 1
