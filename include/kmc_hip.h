@@ -167,12 +167,12 @@ int kmc_table_is_compact(kmc_ctx* ctx);
  * replicas 2 = the 8-replicas-per-CU kernel (kmc_hop_lds64.h), 3 = the 16-per-CU kernel (kmc_hop_q64.h);
  * the default is 3.  No counterpart in the reference. */
 int kmc_set_hop_kernel(kmc_ctx* ctx, int which);
-/* Launch groups of the 16-per-CU kernel.  mode 2: every run is launched as two kernels over the two halves of
- * the replicas, each on a stream of its own, and consecutive runs are not joined (a group's next launch waits
- * for that group's last one only), so one group's start-up, write-back and tail overlap the other's hop loop;
- * every other entry point joins the groups first, results are those of one launch.  mode 1: one launch.
- * mode 0 (default): two groups when the replicas exceed 3/4 of one resident round (3072).  No counterpart
- * in the reference. */
+/* Launch groups of the LDS-resident hop kernels (lattices up to 64 x 64).  mode 2: every run is launched as two
+ * kernels over the two halves of the replicas, each on a stream of its own, and consecutive runs are not joined
+ * (a group's next launch waits for that group's last one only), so one group's start-up, write-back and tail
+ * overlap the other's hop loop; every other entry point joins the groups first, results are those of one
+ * launch.  mode 1: one launch.  mode 0 (default): two groups when the replicas exceed 3/4 of the workgroups the
+ * chip holds at once (3072 for the default 64 x 64 kernel).  No counterpart in the reference. */
 int kmc_set_launch_groups(kmc_ctx* ctx, int mode);
 /* profiling builds only (-DKMC_STAMPS): cycles [R][8] the last kmc_run spent per hop segment, measured
  * with s_memtime; any other build returns KMC_ESTATE.  No counterpart in the reference. */

@@ -41,7 +41,7 @@ struct kmc_ctx {
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     bool timed;
-    // A run of the 16-per-CU kernel over more replicas than ~3/4 of one resident round is launched as
+    // A run of an LDS hop kernel over more replicas than 3/4 of one resident round is launched as
     // KMC_GROUPS kernels over disjoint replica ranges, each on a stream of its own.  Consecutive runs are NOT
     // joined: group g's next launch waits for group g's last one only, so the groups drift apart and one's
     // prologue / epilogue / tail overlaps the other's hop loop (+8 % at 4096 replicas, +35 % at 4608).  Every
@@ -1079,8 +1079,11 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     p.tcompact = c->tcompact;
     p.xscratch = c->xscratch;
     p.tcompact2 = c->tcompact2;
-    // more than 12 replicas per CU (3 waves per SIMD) of the 16-per-CU kernel: two launch groups (see kmc_ctx)
-    const bool split = c->lds64 && c->q64 && c->R >= 2 * 8 && (c->split == 2 || (c->split == 0 && c->R > 3072));
+    // More replicas than 3/4 of the workgroups the chip holds at once: two launch groups (see kmc_ctx).  Resident
+    // workgroups per CU: 16 (hop_q64_kernel), 8 (hop_lds64_kernel); the any-size kernel runs 3 waves per SIMD.
+    const size_t gen_lds = host_hop_lds_bytes(c->nx, c->n);
+    const int per_cu = c->lds64 ? (c->q64 ? 16 : 8) : (gen_lds * 12 <= 160 * 1024 ? 12 : (int)((160 * 1024) / gen_lds));
+    const bool split = c->R >= 2 * 8 && (c->split == 2 || (c->split == 0 && c->R > 192 * per_cu));
     if (split) {
         if (c->need_fork) {
             HIPCHK(c, hipEventRecord(c->fork_ev, c->stream));
@@ -1092,14 +1095,21 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         for (int g = 0; g < KMC_GROUPS; ++g) {
             p.r_base = g == 0 ? 0 : r_half;
             const int rg = g == 0 ? r_half : c->R - r_half;
-            if (g == 0) hipEventRecord(c->ev0, c->gstream[0]);
-            HIPCHK(c, hipEventRecord(c->run_ev[slot][g][0], c->gstream[g]));
-            if (c->have_compact)
-                hop_q64_kernel<true><<<rg, 64, Q64_LDS_BYTES, c->gstream[g]>>>(p);
+            hipStream_t gs = c->gstream[g];
+            if (g == 0) hipEventRecord(c->ev0, gs);
+            HIPCHK(c, hipEventRecord(c->run_ev[slot][g][0], gs));
+            if (c->lds64 && c->q64 && c->have_compact)
+                hop_q64_kernel<true><<<rg, 64, Q64_LDS_BYTES, gs>>>(p);
+            else if (c->lds64 && c->q64)
+                hop_q64_kernel<false><<<rg, 64, Q64_LDS_BYTES, gs>>>(p);
+            else if (c->lds64 && c->have_compact)
+                hop_lds64_kernel<true><<<rg, 64, K64_LDS_BYTES, gs>>>(p);
+            else if (c->lds64)
+                hop_lds64_kernel<false><<<rg, 64, K64_LDS_BYTES, gs>>>(p);
             else
-                hop_q64_kernel<false><<<rg, 64, Q64_LDS_BYTES, c->gstream[g]>>>(p);
-            HIPCHK(c, hipEventRecord(c->run_ev[slot][g][1], c->gstream[g]));
-            if (g == 0) { hipEventRecord(c->ev1, c->gstream[0]); c->timed = true; c->timed_slot = slot; }
+                hop_lds_kernel<<<rg, 64, gen_lds, gs>>>(p);
+            HIPCHK(c, hipEventRecord(c->run_ev[slot][g][1], gs));
+            if (g == 0) { hipEventRecord(c->ev1, gs); c->timed = true; c->timed_slot = slot; }
         }
         c->groups_busy = true;
         ++c->run_launches;

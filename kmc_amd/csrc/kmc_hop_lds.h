@@ -66,7 +66,7 @@ struct HopParams {
     long long* stamps;           // [R][8] cycles per segment (-DKMC_STAMPS profiling builds only) or null
     void* xscratch;              // [R][Q64_XSCRATCH] exact-path scratch of hop_q64_kernel
     const double* tcompact2;     // [3][2^15][2] pair tables (hop_q64_kernel<true>) or null
-    int r_base;                  // hop_q64_kernel: replica of block 0 (a run may be launched as several groups)
+    int r_base;                  // replica of block 0 (a run may be launched as several groups)
 };
 
 // Profiling builds (-DKMC_STAMPS, scripts/stamps.py) time the segments of a hop with s_memtime.
@@ -141,7 +141,7 @@ __host__ __device__ inline size_t hop_lds_layout(int nx, int n, size_t* off_blk,
 __global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int r = blockIdx.x, lane = threadIdx.x;
+    const int r = blockIdx.x + p.r_base, lane = threadIdx.x;
     const int nx = p.nx, ny = p.ny, n = p.n;
     size_t off_blk, off_col, off_frames;
     hop_lds_layout(nx, n, &off_blk, &off_col, &off_frames);

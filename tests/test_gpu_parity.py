@@ -586,10 +586,12 @@ def test_full_size_ensemble_two_kernels(kmc, tables):
 
 
 # ---------------------------------------------------------------- launch groups
-def test_launch_groups_equal_one_launch(kmc, tables):
+@pytest.mark.parametrize('n,which', [(64, 3), (64, 2), (30, 0)], ids=['q64', 'lds64', 'lds-30x30'])
+def test_launch_groups_equal_one_launch(kmc, tables, n, which):
     """kmc_set_launch_groups: a run launched as two kernels over the two halves of the replicas, runs not
     joined in between, is the same computation replica by replica -- every output bit-identical to one launch
-    per run; injected draws, traces, per-replica hop counts and the free-running Philox sequence."""
+    per run; injected draws, traces, per-replica hop counts and the free-running Philox sequence.  Every LDS
+    hop kernel."""
     R, seed = 77, 0xABCDEF                                   # odd: unequal halves (40 + 37)
     conc = np.tile(np.linspace(0.1, 0.9, 9), R // 9 + 1)[:R]
     rs = np.random.RandomState(5)
@@ -597,7 +599,8 @@ def test_launch_groups_equal_one_launch(kmc, tables):
     counts = rs.randint(0, 3000, size=R)
     out = []
     for mode in (1, 2):
-        with make_engine(kmc, tables, R, 64, 64) as eng:
+        with make_engine(kmc, tables, R, n, n) as eng:
+            eng.set_hop_kernel(which=which)
             eng.set_launch_groups(mode)
             eng.fill_random(conc, 17)
             eng.rates_full()
