@@ -549,6 +549,7 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, K64_LDS_BYTES));
         const size_t lds = host_hop_lds_bytes(c->nx, c->n);
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds_kernel_w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else {
         if (nx <= 4096) {
             const size_t lds = ((sizeof(GbShared) + 15) & ~(size_t)15) + (size_t)nx * 8;
@@ -1082,7 +1083,10 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     // More replicas than 3/4 of the workgroups the chip holds at once: two launch groups (see kmc_ctx).  Resident
     // workgroups per CU: 16 (hop_q64_kernel), 8 (hop_lds64_kernel); the any-size kernel runs 3 waves per SIMD.
     const size_t gen_lds = host_hop_lds_bytes(c->nx, c->n);
-    const int per_cu = c->lds64 ? (c->q64 ? 16 : 8) : (gen_lds * 12 <= 160 * 1024 ? 12 : (int)((160 * 1024) / gen_lds));
+    // 16 replicas fit a CU and there are more than the 3-wave build holds at once (12 per CU): the 4-waves-per-SIMD
+    // build; below that its spills only cost (a single 30 x 30 lattice: -4 %)
+    const bool gen_w4 = gen_lds * 16 <= 160 * 1024 && c->R > 256 * 12;
+    const int per_cu = c->lds64 ? (c->q64 ? 16 : 8) : (gen_w4 ? 16 : (gen_lds * 12 <= 160 * 1024 ? 12 : (int)((160 * 1024) / gen_lds)));
     const bool split = c->R >= 2 * 8 && (c->split == 2 || (c->split == 0 && c->R > 192 * per_cu));
     if (split) {
         if (c->need_fork) {
@@ -1106,6 +1110,8 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
                 hop_lds64_kernel<true><<<rg, 64, K64_LDS_BYTES, gs>>>(p);
             else if (c->lds64)
                 hop_lds64_kernel<false><<<rg, 64, K64_LDS_BYTES, gs>>>(p);
+            else if (gen_w4)
+                hop_lds_kernel_w4<<<rg, 64, gen_lds, gs>>>(p);
             else
                 hop_lds_kernel<<<rg, 64, gen_lds, gs>>>(p);
             HIPCHK(c, hipEventRecord(c->run_ev[slot][g][1], gs));
@@ -1136,8 +1142,10 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         hop_lds64_kernel<true><<<c->R, 64, K64_LDS_BYTES, c->stream>>>(p);
     else if (c->lds64)
         hop_lds64_kernel<false><<<c->R, 64, K64_LDS_BYTES, c->stream>>>(p);
+    else if (gen_w4)
+        hop_lds_kernel_w4<<<c->R, 64, gen_lds, c->stream>>>(p);
     else
-        hop_lds_kernel<<<c->R, 64, host_hop_lds_bytes(c->nx, c->n), c->stream>>>(p);
+        hop_lds_kernel<<<c->R, 64, gen_lds, c->stream>>>(p);
     HIPCHK(c, hipEventRecord(c->run_ev[slot][0][1], c->stream));
     time_end(c);
     ++c->run_launches;

@@ -130,17 +130,28 @@ __host__ __device__ inline size_t hop_lds_layout(int nx, int n, size_t* off_blk,
     return o;
 }
 
-#ifdef KMC_LDS_WAVES            // occupancy experiments only (scripts/probe_occupancy.py)
-#define KMC_LDS_ATTR __attribute__((amdgpu_waves_per_eu(KMC_LDS_WAVES, KMC_LDS_WAVES)))
-#else
-// at least 3 waves per SIMD (<= 168 registers): the budget also binds the exact path the kernel calls,
-// which would take 226 registers left alone; small lattices run 12 replicas per CU
-#define KMC_LDS_ATTR __attribute__((amdgpu_waves_per_eu(3)))
-#endif
+// Two builds of one body.  hop_lds_kernel: at least 3 waves per SIMD (<= 168 registers; the budget also binds the
+// exact path the kernel calls, which would take 226 registers left alone), 12 replicas per CU.  hop_lds_kernel_w4:
+// 4 waves per SIMD (128 registers, a few spilled), for lattices whose LDS footprint lets 16 replicas share a CU
+// (<= 10 KB: up to 38 x 38) when there are more replicas than 12 per CU: +12 ... +26 % on ensembles of 10 x 10 ...
+// 32 x 32, while at 40 x 40 and beyond (15 or fewer per CU anyway) the spills cost 8-14 %, and a single lattice
+// (latency-bound) loses 4 %: there the 3-wave build stays.
+static __device__ __forceinline__ void hop_lds_body(const HopParams& p, unsigned char* smem);
 
-__global__ __launch_bounds__(64) KMC_LDS_ATTR void hop_lds_kernel(HopParams p)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void hop_lds_kernel(HopParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    hop_lds_body(p, smem);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void hop_lds_kernel_w4(HopParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    hop_lds_body(p, smem);
+}
+
+static __device__ __forceinline__ void hop_lds_body(const HopParams& p, unsigned char* smem)
+{
     const int r = blockIdx.x + p.r_base, lane = threadIdx.x;
     const int nx = p.nx, ny = p.ny, n = p.n;
     size_t off_blk, off_col, off_frames;

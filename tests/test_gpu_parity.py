@@ -640,3 +640,33 @@ def test_launch_group_controls_reject_bad_arguments(kmc, tables):
         with pytest.raises(kmc.engine.KMCError):
             eng.run_span_ms(65)
         assert (eng.status()['hops_done'] == 10).all()
+
+
+def test_any_size_kernel_two_builds_agree(kmc, tables, dense):
+    """The any-size LDS kernel exists in a 3- and a 4-waves-per-SIMD build (kmc_hop_lds.h); the engine takes the
+    second for ensembles of more than 3072 small lattices.  Same source, so the same bits: 3200 replicas of 12 x 12
+    (4-wave build) against the same replicas run 1600 at a time (3-wave build), and a sample against the oracle."""
+    R, n, hp, hs, seed = 3200, 12, 300, 500, 77
+    conc = np.tile(np.linspace(0.1, 0.9, 9), R // 9 + 1)[:R]
+    def run(lo, hi):
+        with make_engine(kmc, tables, hi - lo, n, n) as eng:
+            occ = np.stack([PH.fill_lattice(5, r, n, n, conc[r]) for r in range(lo, hi)])
+            eng.set_lattice(occ)
+            eng.rates_full()
+            d = np.stack([PH.hop_draws(seed, r, 0, hp + hs) for r in range(lo, hi)])
+            eng.run(hp, presim=True, draws=d[:, :hp])
+            eng.init_displacements()
+            eng.run(hs, presim=False, draws=d[:, hp:])
+            sc = eng.scalars()
+            return eng.get_lattice(), eng.get_keys(), eng.get_displacements(), sc['hist'], sc['time'], sc['gamma'], occ, d
+    big = run(0, R)
+    halves = [run(0, R // 2), run(R // 2, R)]
+    for k in range(6):
+        assert np.array_equal(big[k], np.concatenate([h[k] for h in halves])), k
+    for r in (0, 1777, R - 1):
+        rep = CO.Replica(big[6][r], dense, 'hex_ref')
+        rep.run(big[7][r, :hp], True)
+        rep.init_tags()
+        rep.run(big[7][r, hp:], False)
+        assert np.array_equal(big[0][r], rep.occ) and np.array_equal(big[3][r], rep.hist.astype(np.int64))
+        np.testing.assert_allclose(big[4][r], rep.time.value, rtol=RTOL)
