@@ -12,7 +12,8 @@ src = os.path.join(ROOT, 'gpurun_out', 'prof_' + tag)
 dst = os.path.join(ROOT, 'profiles')
 stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))[0]
 shutil.copy(stats, os.path.join(dst, tag + '_kernel_stats.csv'))
-out = {'tag': tag, 'kernel': kern, 'command': 'python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline', 'counters': {}}
+out = {'tag': tag, 'kernel': kern, 'command': 'kernel trace: python3 bench.py --no-cpu-baseline (40 + 10 steps); '
+       'counters: python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline', 'counters': {}}
 for row in csv.DictReader(open(stats)):
     if kern in row['Name']:
         out['kernel_trace'] = {'calls': int(row['Calls']), 'avg_ms': float(row['AverageNs']) / 1e6,
