@@ -650,6 +650,7 @@ def test_any_size_kernel_two_builds_agree(kmc, tables, dense):
     conc = np.tile(np.linspace(0.1, 0.9, 9), R // 9 + 1)[:R]
     def run(lo, hi):
         with make_engine(kmc, tables, hi - lo, n, n) as eng:
+            eng.set_debug(force_exact=False, margin_scale=5e7)          # some hops take the exact path
             occ = np.stack([PH.fill_lattice(5, r, n, n, conc[r]) for r in range(lo, hi)])
             eng.set_lattice(occ)
             eng.rates_full()
@@ -658,6 +659,7 @@ def test_any_size_kernel_two_builds_agree(kmc, tables, dense):
             eng.init_displacements()
             eng.run(hs, presim=False, draws=d[:, hp:])
             sc = eng.scalars()
+            assert eng.status()["n_exact"].sum() > 100
             return eng.get_lattice(), eng.get_keys(), eng.get_displacements(), sc['hist'], sc['time'], sc['gamma'], occ, d
     big = run(0, R)
     halves = [run(0, R // 2), run(R // 2, R)]
