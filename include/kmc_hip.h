@@ -128,6 +128,11 @@ int kmc_run_counts(kmc_ctx* ctx, const int64_t* n_hops /* [R] */, int presim, ui
  * hist [R][6]: hop_histogram (:535).  Any pointer may be NULL. */
 int kmc_get_scalars(kmc_ctx* ctx, double* time, double* step_time, double* gamma, int64_t* hist);
 int kmc_set_time(kmc_ctx* ctx, const double* time /* [R] */);
+/* Resuming a saved state (the reference's state is the arrays kmc_step takes and returns, :470, :539: lattice,
+ * rate matrix = keys here, distance_lattice, total_time, hop_histogram): hops_done [R] = each replica's position in
+ * the Philox stream of kmc_run without injected draws, hist [R][6].  Either pointer may be NULL.  With
+ * kmc_set_lattice, kmc_set_keys, kmc_set_displacements and kmc_set_time a run continues bit for bit. */
+int kmc_set_counters(kmc_ctx* ctx, const int64_t* hops_done, const int64_t* hist);
 /* chosen_barrier (:495-498): last, and sum / min / max / count over the hops of
  * all kmc_run calls since kmc_init_displacements; out = [R][5] */
 int kmc_get_barrier_stats(kmc_ctx* ctx, double* out);

@@ -47,6 +47,7 @@ SIGNATURES = {
     'kmc_run_counts': (C.c_int, [_ctx, _i64p, C.c_int, C.c_uint64]),
     'kmc_get_scalars': (C.c_int, [_ctx, _dp, _dp, _dp, _i64p]),
     'kmc_set_time': (C.c_int, [_ctx, _dp]),
+    'kmc_set_counters': (C.c_int, [_ctx, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'kmc_get_barrier_stats': (C.c_int, [_ctx, _dp]),
     'kmc_get_status': (C.c_int, [_ctx, _i32p, _i64p, _i64p]),
     'kmc_gamma_exact': (C.c_int, [_ctx, _dp]),

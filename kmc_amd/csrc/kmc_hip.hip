@@ -1210,6 +1210,21 @@ int kmc_set_time(kmc_ctx* c, const double* time)
     return KMC_OK;
 }
 
+// Resuming a checkpoint: the hops each replica has done (= its position in the Philox stream of kmc_run without
+// injected draws) and its direction histogram.  Either pointer may be null.
+int kmc_set_counters(kmc_ctx* c, const int64_t* hops_done, const int64_t* hist)
+{
+    CTXCHK(c);
+    if (hops_done) {
+        for (int r = 0; r < c->R; ++r)
+            if (hops_done[r] < 0) return fail(c, KMC_EINVAL, "kmc_set_counters: negative hop count for replica %d", r);
+        HIPCHK(c, hipMemcpyAsync(c->hops_done, hops_done, c->R * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    if (hist) HIPCHK(c, hipMemcpyAsync(c->hist, hist, c->R * 48, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+}
+
 int kmc_get_barrier_stats(kmc_ctx* c, double* out)
 {
     CTXCHK(c);

@@ -224,6 +224,34 @@ class KMCEngine:
         t = np.ascontiguousarray(np.broadcast_to(np.asarray(time, dtype=np.float64), (self.R,)))
         self._chk(self._lib.kmc_set_time(self._ctx, _ptr(t, C.c_double)))
 
+    def set_counters(self, hops_done=None, hist=None):
+        h = None if hops_done is None else np.ascontiguousarray(np.broadcast_to(np.asarray(hops_done, dtype=np.int64), (self.R,)))
+        g = None if hist is None else np.ascontiguousarray(hist, dtype=np.int64).reshape(self.R, 6)
+        self._chk(self._lib.kmc_set_counters(self._ctx, _ptr(h, C.c_int64), _ptr(g, C.c_int64)))
+
+    # -- checkpoint / resume -------------------------------------------------------
+    def checkpoint(self):
+        """Everything a run continues from, as numpy arrays (np.savez(path, **eng.checkpoint()) is a checkpoint file):
+        the arrays the reference's kmc_step takes and returns (hex_LiCoO2_kmc.py:470, :539) -- lattice, rate matrix
+        (as the keys it is a function of), distance_lattice, total_time, hop_histogram -- and each replica's hop count,
+        which is its position in the Philox stream.  The chosen-barrier statistics are diagnostics and start afresh."""
+        sc, st = self.scalars(), self.status()
+        if st['status'].any():
+            raise ReplicaStopped(-4, 'checkpoint: replicas have stopped (status %r)' % np.unique(st['status']))
+        return dict(nx=np.int64(self.nx), ny=np.int64(self.ny), lattice=self.get_lattice(), keys=self.get_keys(),
+                    displacements=self.get_displacements(), time=sc['time'], hist=sc['hist'], hops_done=st['hops_done'])
+
+    def restore(self, ck):
+        """Load a checkpoint() (or the np.load of one) into this engine: same replica count and lattice size;
+        the rate table is set separately, as always."""
+        if int(ck['nx']) != self.nx or int(ck['ny']) != self.ny or np.asarray(ck['lattice']).shape[0] != self.R:
+            raise ValueError('checkpoint is for %d replicas of %d x %d' % (np.asarray(ck['lattice']).shape[0], int(ck['nx']), int(ck['ny'])))
+        self.set_lattice(ck['lattice'])
+        self.set_keys(ck['keys'])
+        self.set_displacements(ck['displacements'])
+        self.set_time(ck['time'])
+        self.set_counters(ck['hops_done'], ck['hist'])
+
     def barrier_stats(self):
         b = np.empty((self.R, 5))
         self._chk(self._lib.kmc_get_barrier_stats(self._ctx, _ptr(b, C.c_double)))

@@ -672,3 +672,40 @@ def test_any_size_kernel_two_builds_agree(kmc, tables, dense):
         rep.run(big[7][r, hp:], False)
         assert np.array_equal(big[0][r], rep.occ) and np.array_equal(big[3][r], rep.hist.astype(np.int64))
         np.testing.assert_allclose(big[4][r], rep.time.value, rtol=RTOL)
+
+
+# ---------------------------------------------------------------- checkpoint / resume
+@pytest.mark.parametrize('nx,ny,R', [(64, 64, 5), (30, 30, 4), (70, 66, 2)], ids=['q64', 'lds-30x30', 'big-70x66'])
+def test_checkpoint_resume_continues_bit_for_bit(kmc, tables, tmp_path, nx, ny, R):
+    """The reference's state is the arrays kmc_step takes and returns (hex_LiCoO2_kmc.py:470, :539); saved with
+    np.savez and restored into a NEW engine (plus each replica's position in the Philox stream), the run goes on
+    exactly as the uninterrupted one: stale keys, displacement tags, clocks and histograms included."""
+    conc = np.linspace(0.3, 0.7, R)
+    seed = 4242
+    with make_engine(kmc, tables, R, nx, ny) as a:
+        a.fill_random(conc, 3)
+        a.rates_full()
+        a.run(300, presim=True, seed=seed)
+        a.init_displacements()
+        a.run(400, presim=False, seed=seed)
+        path = str(tmp_path / 'state.npz')
+        np.savez(path, **a.checkpoint())
+        a.run(500, presim=False, seed=seed)
+        a.run(77, presim=False, seed=seed)
+        sc, st = a.scalars(), a.status()
+        want = (a.get_lattice(), a.get_keys(), a.get_displacements(), sc['time'], sc['hist'], st['hops_done'],
+                a.diffusion(conc)[0], a.gamma_exact())
+    with make_engine(kmc, tables, R, nx, ny) as b:
+        with np.load(path) as ck:
+            b.restore(ck)
+        b.run(500, presim=False, seed=seed)
+        b.run(77, presim=False, seed=seed)
+        sc, st = b.scalars(), b.status()
+        got = (b.get_lattice(), b.get_keys(), b.get_displacements(), sc['time'], sc['hist'], st['hops_done'],
+               b.diffusion(conc)[0], b.gamma_exact())
+    for k, (x, y) in enumerate(zip(got, want)):
+        assert np.array_equal(x, y), k
+    assert (got[5] == 300 + 400 + 577).all()
+    with make_engine(kmc, tables, R + 1, nx, ny) as c:
+        with np.load(path) as ck, pytest.raises(ValueError):
+            c.restore(ck)
