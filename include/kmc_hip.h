@@ -152,6 +152,18 @@ int kmc_set_debug(kmc_ctx* ctx, int force_exact, double margin_scale);
 int kmc_diffusion(kmc_ctx* ctx, const double* conc /* [R] */, double lattice_constant,
                   double* dstar /* [R] */, double* dj /* [R] */, double* msd_out);
 
+/* kmc_diffusion for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for code under HIP
+ * graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same result as kmc_diffusion, but
+ *   - conc_dev, dstar_dev, dj_dev, msd_dev (or NULL) are DEVICE pointers on the context's GPU ([R], [R], [R], [R][4]);
+ *   - the per-replica sums go through a static device array of the library (2 MiB per GPU, held until the
+ *     process ends) instead of a buffer allocated per call: at most 65536 replicas, more is KMC_EINVAL;
+ *   - the call only enqueues two kernels on the context's stream: no allocation, no free, no copy, no wait
+ *     (kmc_sync, or any stream-ordered reader, before the results are used);
+ *   - a replica of concentration 0 gets NaN (kmc_diffusion returns the reference's sys.exit text instead).
+ * Every call on one GPU shares that GPU's array: calls from different contexts that overlap on one GPU race. */
+int kmc_diffusion_noalloc(kmc_ctx* ctx, const double* conc_dev, double lattice_constant,
+                          double* dstar_dev, double* dj_dev, double* msd_dev);
+
 /* get_distance, hex_LiCoO2_kmc.py:558-586: distances_travelled_matrix * a per site
  * (0 where vacant); the list and the vector sum follow from it and msd_out. */
 int kmc_get_distances(kmc_ctx* ctx, double lattice_constant, double* matrix /* [R][nx][ny] */);

@@ -53,6 +53,7 @@ SIGNATURES = {
     'kmc_gamma_exact': (C.c_int, [_ctx, _dp]),
     'kmc_set_debug': (C.c_int, [_ctx, C.c_int, C.c_double]),
     'kmc_diffusion': (C.c_int, [_ctx, _dp, C.c_double, _dp, _dp, _dp]),
+    'kmc_diffusion_noalloc': (C.c_int, [_ctx, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     'kmc_get_distances': (C.c_int, [_ctx, C.c_double, _dp]),
     'kmc_uses_lds_path': (C.c_int, [_ctx]),
     'kmc_lds_bytes': (C.c_int, [_ctx]),

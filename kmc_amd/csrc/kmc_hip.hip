@@ -72,6 +72,7 @@ struct kmc_ctx {
     int* status;
     double* barrier;
     double* scratch_d;     // [R*8] small per-replica scratch
+    long long* noalloc_scratch;   // this device's address of kmc_noalloc_scratch (kmc_diffusion_noalloc)
     double* w_g;           // [R][n] per-site rate sums, global-memory hop kernel only (lazy)
     // per-call staging
     double* draws; size_t draws_cap;
@@ -447,6 +448,38 @@ __global__ __launch_bounds__(64) void gamma_exact_kernel(const uint32_t* __restr
     gamma[r] = np_sum_model(6L * n, entry, st);
 }
 
+// Finishing step of kmc_diffusion_noalloc: the host arithmetic of kmc_diffusion (hex_LiCoO2_kmc.py:591-602),
+// one lane per replica, from the exact integer sums msd_kernel left in `part`.
+__global__ __launch_bounds__(256) void diffusion_finalize_kernel(const long long* __restrict__ part,
+                                                                  const double* __restrict__ time_total,
+                                                                  const double* __restrict__ conc, int R, int nx, int ny,
+                                                                  double a, double* __restrict__ dstar, double* __restrict__ dj,
+                                                                  double* __restrict__ msd_out)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const double n_atoms = (double)nx * ny * 1 * conc[r];                  // a float in the reference
+    const double sq = (double)part[r * 4], si = (double)part[r * 4 + 1], sj = (double)part[r * 4 + 2], cnt = (double)part[r * 4 + 3];
+    if (msd_out) { msd_out[r * 4] = sq; msd_out[r * 4 + 1] = si; msd_out[r * 4 + 2] = sj; msd_out[r * 4 + 3] = cnt; }
+    if (n_atoms == 0) {                                                     // "concentration is zero, no atoms to move!"
+        dstar[r] = __longlong_as_double(0x7FF8000000000000LL);
+        dj[r] = __longlong_as_double(0x7FF8000000000000LL);
+        return;
+    }
+    const double mean_sq = (a * a) * sq / cnt;
+    const double dj2 = (a * a) * fabs(si * si + sj * sj + si * sj);
+    const double pref = 1 / (2 * 2 * time_total[r] / n_atoms);
+    dstar[r] = pref * mean_sq;
+    dj[r] = pref * dj2 / n_atoms;
+}
+
+// Scratch of kmc_diffusion_noalloc: the per-replica integer sums of msd_kernel ([R][4] i64), which kmc_diffusion
+// keeps in a buffer it allocates per call.  One array per GPU the library runs on (2 MiB), held until the process
+// ends.  Host code never uses this NAME as an address: kmc_create asks hipGetSymbolAddress for the array's address
+// on the context's device and kernels / memsets take that pointer.
+#define KMC_NOALLOC_MAX_REPLICAS 65536
+static __device__ __align__(256) long long kmc_noalloc_scratch[(size_t)KMC_NOALLOC_MAX_REPLICAS * 4];
+
 // ======================================================================
 // host API
 // ======================================================================
@@ -528,6 +561,12 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     CREATE_CHK(hipMalloc((void**)&c->status, c->R * 4));
     CREATE_CHK(hipMalloc((void**)&c->barrier, c->R * 5 * 8));
     CREATE_CHK(hipMalloc((void**)&c->scratch_d, c->R * 8 * 8));
+    {
+        // each GPU holds its own copy of the array at its own address: asked for with THIS device current
+        void* sp = nullptr;
+        CREATE_CHK(hipGetSymbolAddress(&sp, HIP_SYMBOL(kmc_noalloc_scratch)));
+        c->noalloc_scratch = static_cast<long long*>(sp);
+    }
     CREATE_CHK(hipMemsetAsync(c->occ, 0, Rn, c->stream));
     CREATE_CHK(hipMemsetAsync(c->keys, 0xFF, Rn * 4, c->stream));
     CREATE_CHK(hipMemsetAsync(c->tags, 0, Rn * 16, c->stream));
@@ -1291,6 +1330,27 @@ int kmc_diffusion(kmc_ctx* c, const double* conc, double a, double* dstar, doubl
     }
     free(h); free(t);
     return rc;
+}
+
+// kmc_diffusion for callers that cannot allocate (code under HIP graph capture, tight serving loops): every
+// pointer is DEVICE memory on the context's GPU, the per-replica sums go through the library's static scratch
+// array, everything is enqueued on the context's stream and nothing is allocated, freed or waited for.
+int kmc_diffusion_noalloc(kmc_ctx* c, const double* conc_dev, double a, double* dstar_dev, double* dj_dev, double* msd_dev)
+{
+    CTXCHK(c);
+    if (!conc_dev || !dstar_dev || !dj_dev) return fail(c, KMC_EINVAL, "kmc_diffusion_noalloc: null pointer");
+    if (c->R > KMC_NOALLOC_MAX_REPLICAS)
+        return fail(c, KMC_EINVAL, "kmc_diffusion_noalloc: %d replicas exceed the %d the library's static scratch holds; use kmc_diffusion",
+                    c->R, KMC_NOALLOC_MAX_REPLICAS);
+    long long* part = c->noalloc_scratch;
+    if (!part) return fail(c, KMC_ESTATE, "kmc_diffusion_noalloc: the scratch array's device address is unknown");
+    // every call on this GPU shares the array and finds the last call's sums in it: msd_kernel overwrites all of
+    // [0, R) x 4, the part this call reads, so nothing needs clearing
+    msd_kernel<<<c->R, 256, 0, c->stream>>>(c->tags, c->nx, c->ny, part);
+    diffusion_finalize_kernel<<<(c->R + 255) / 256, 256, 0, c->stream>>>(part, c->time_total, conc_dev, c->R, c->nx, c->ny, a,
+                                                                         dstar_dev, dj_dev, msd_dev);
+    HIPCHK(c, hipGetLastError());
+    return KMC_OK;
 }
 
 int kmc_get_distances(kmc_ctx* c, double a, double* matrix)

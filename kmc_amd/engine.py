@@ -292,6 +292,13 @@ class KMCEngine:
                                           _ptr(ds, C.c_double), _ptr(dj, C.c_double), _ptr(msd, C.c_double)))
         return ds, dj, msd
 
+    def diffusion_noalloc(self, conc_dev, dstar_dev, dj_dev, msd_dev=None, lattice_constant=LATTICE_CONSTANT):
+        """kmc_diffusion_noalloc (include/kmc_hip.h): the arguments are DEVICE addresses (ints) on this engine's GPU;
+        the call enqueues on the engine's stream and returns at once -- sync() before reading the results."""
+        self._chk(self._lib.kmc_diffusion_noalloc(self._ctx, C.c_void_p(int(conc_dev)), float(lattice_constant),
+                                                  C.c_void_p(int(dstar_dev)), C.c_void_p(int(dj_dev)),
+                                                  C.c_void_p(int(msd_dev)) if msd_dev else None))
+
     def distances(self, lattice_constant=LATTICE_CONSTANT):
         """distances_travelled_matrix * a (hex_LiCoO2_kmc.py:577-578), (R, nx, ny)."""
         m = np.empty(self._shape(), dtype=np.float64)
