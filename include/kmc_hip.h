@@ -82,6 +82,12 @@ int kmc_get_lattice(kmc_ctx* ctx, int8_t* occ);
  * Philox4x32-10 keyed by (seed, replica): the fill loop hex_LiCoO2_kmc.py:703-714 */
 int kmc_fill_random(kmc_ctx* ctx, const double* conc /* [R] */, uint64_t seed);
 
+/* The ensemble loops hex_LiCoO2_kmc.py:679-693 sharded over several contexts (GPUs): this context's replica 0 is
+ * replica `offset` of the whole ensemble.  kmc_fill_random and the Philox draws of kmc_run / kmc_run_counts are keyed
+ * by (seed, offset + r, counter), so with ONE seed the ensemble is the same at any GPU count (two contexts of R/2 with
+ * offsets 0 and R/2 reproduce one context of R bit for bit).  Default 0; offset + R must fit 32 bits. */
+int kmc_set_replica_offset(kmc_ctx* ctx, uint64_t offset);
+
 /* ---- rates (rows R1-R3) ------------------------------------------------ */
 /* kmc_evolve(..., use_initialize_mode=True), hex_LiCoO2_kmc.py:435-443, :453-465,
  * for every replica: 18-bit keys (get_hex_probability :418-428) + rate gather. */

@@ -34,6 +34,7 @@ SIGNATURES = {
     'kmc_set_lattice': (C.c_int, [_ctx, _i8p]),
     'kmc_get_lattice': (C.c_int, [_ctx, _i8p]),
     'kmc_fill_random': (C.c_int, [_ctx, _dp, C.c_uint64]),
+    'kmc_set_replica_offset': (C.c_int, [_ctx, C.c_uint64]),
     'kmc_rates_full': (C.c_int, [_ctx]),
     'kmc_get_keys': (C.c_int, [_ctx, _u32p]),
     'kmc_set_keys': (C.c_int, [_ctx, _u32p]),

@@ -80,6 +80,7 @@ struct kmc_ctx {
     bool have_table, have_keys;
     int force_exact;
     double margin_scale;
+    uint32_t rid_base;     // kmc_set_replica_offset: global id of replica 0 (Philox counter word)
     char err[512];
 };
 
@@ -107,7 +108,6 @@ static int fail(kmc_ctx* ctx, int code, const char* fmt, ...)
 static hipError_t join_groups(kmc_ctx* c)
 {
     c->need_fork = true;
-    c->timed_slot = -1;                 // whoever joins is about to put work on the context's stream
     if (!c->groups_busy) return hipSuccess;
     for (int g = 0; g < KMC_GROUPS; ++g) {
         hipError_t e = hipEventRecord(c->gdone[g], c->gstream[g]);
@@ -339,12 +339,12 @@ __global__ void site_probability_kernel(const uint8_t* __restrict__ occ, int nx,
 // draws a 64-bit Philox key; the n_li smallest keys (ties by site index) get Li.
 // One wave per replica; the threshold is found by bisection on the key value.
 __global__ __launch_bounds__(64) void fill_random_kernel(uint8_t* __restrict__ occ, int n, const int* __restrict__ n_li,
-                                                          uint32_t seed_lo, uint32_t seed_hi)
+                                                          uint32_t seed_lo, uint32_t seed_hi, uint32_t rid_base)
 {
     const int r = blockIdx.x, lane = threadIdx.x;
     const int want = n_li[r];
     auto site_key64 = [&](int s) -> unsigned long long {
-        u32x4 c; c.x = (uint32_t)s; c.y = 0; c.z = (uint32_t)r; c.w = KMC_STREAM_FILL;
+        u32x4 c; c.x = (uint32_t)s; c.y = 0; c.z = (uint32_t)r + rid_base; c.w = KMC_STREAM_FILL;
         const u32x4 o = philox4x32_10(c, seed_lo, seed_hi);
         return ((unsigned long long)o.x << 32) | o.y;
     };
@@ -641,7 +641,7 @@ int kmc_sync(kmc_ctx* c)
 
 int kmc_last_kernel_ms(kmc_ctx* c, float* ms)
 {
-    CTXCHK(c);
+    CTXCHK(c);                                  // (timed_slot is reset by the next timed launch, time_begin)
     if (!ms) return fail(c, KMC_EINVAL, "kmc_last_kernel_ms: null pointer");
     if (!c->timed) return fail(c, KMC_ESTATE, "kmc_last_kernel_ms: nothing timed yet");
     HIPCHK(c, hipEventSynchronize(c->ev1));
@@ -720,6 +720,17 @@ int kmc_set_hop_kernel(kmc_ctx* c, int which)
     c->lds64 = c->lds_path && c->nx == 64 && c->ny == 64 && which != 1;
     c->q64 = c->lds64 && (which == 3 || (which == 0 && c->q64_auto));
     c->use_big = c->big_ok && which != 1;
+    return KMC_OK;
+}
+
+// The Philox streams (random fill, per-hop draws) are keyed by (seed, global replica id, counter): a context
+// whose replica 0 is replica `offset` of a larger ensemble draws exactly what that ensemble's one context would.
+int kmc_set_replica_offset(kmc_ctx* c, uint64_t offset)
+{
+    CTXCHK(c);
+    if (offset + (uint64_t)c->R > 0xFFFFFFFFull)
+        return fail(c, KMC_EINVAL, "kmc_set_replica_offset: offset + replicas must fit 32 bits (the Philox counter word)");
+    c->rid_base = (uint32_t)offset;
     return KMC_OK;
 }
 
@@ -834,7 +845,7 @@ int kmc_fill_random(kmc_ctx* c, const double* conc, uint64_t seed)
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     free(h);
     HIPCHK(c, e);
-    fill_random_kernel<<<c->R, 64, 0, c->stream>>>(c->occ, c->n, d, (uint32_t)seed, (uint32_t)(seed >> 32));
+    fill_random_kernel<<<c->R, 64, 0, c->stream>>>(c->occ, c->n, d, (uint32_t)seed, (uint32_t)(seed >> 32), c->rid_base);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_keys = false;
@@ -1047,7 +1058,7 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         g.table = c->table; g.wsum = c->wsum; g.tcompact = c->tcompact; g.occ = c->occ; g.keys = c->keys; g.hier = c->hier;
         g.tags = c->tags;
         g.draws = draws ? c->draws : nullptr; g.sel = sel_out ? c->sel : nullptr;
-        g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32);
+        g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32); g.rid_base = c->rid_base;
         g.time_total = c->time_total; g.step_time = c->step_time; g.gamma = c->gamma; g.hist = c->hist;
         g.hops_done = c->hops_done; g.n_exact = c->n_exact; g.status = c->status; g.barrier = c->barrier;
 #ifdef KMC_STAMPS
@@ -1081,7 +1092,7 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         g.mfac = mfac;
         g.table = c->table; g.wsum = c->wsum; g.occ = c->occ; g.keys = c->keys; g.w = c->w_g; g.tags = c->tags;
         g.draws = draws ? c->draws : nullptr; g.sel = sel_out ? c->sel : nullptr;
-        g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32);
+        g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32); g.rid_base = c->rid_base;
         g.time_total = c->time_total; g.step_time = c->step_time; g.gamma = c->gamma; g.hist = c->hist;
         g.hops_done = c->hops_done; g.n_exact = c->n_exact; g.status = c->status; g.barrier = c->barrier;
         const size_t lds = ((sizeof(GbShared) + 15) & ~(size_t)15) + (size_t)c->nx * 8;
@@ -1109,7 +1120,7 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     p.mfac = mfac;
     p.table = c->table; p.wsum = c->wsum; p.occ = c->occ; p.keys = c->keys; p.tags = c->tags;
     p.draws = draws ? c->draws : nullptr; p.sel = sel_out ? c->sel : nullptr;
-    p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
+    p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32); p.rid_base = c->rid_base;
     p.time_total = c->time_total; p.step_time = c->step_time; p.gamma = c->gamma; p.hist = c->hist;
     p.hops_done = c->hops_done; p.n_exact = c->n_exact; p.status = c->status; p.barrier = c->barrier;
 #ifdef KMC_STAMPS

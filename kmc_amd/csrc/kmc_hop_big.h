@@ -86,6 +86,7 @@ struct HopBigParams {
     double* time_total; double* step_time; double* gamma; long long* hist; long long* hops_done;
     long long* n_exact; int* status; double* barrier;
     long long* stamps;           // [R][8] cycles per segment (-DKMC_STAMPS builds) or null
+    uint32_t rid_base;           // global id of replica 0 (see HopParams)
 };
 
 struct BigCtrl {                 // wave 0 -> the helper waves
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
                     rho_v = dv.x; u_v = dv.y;
                 } else {
                     const unsigned long long hh = (unsigned long long)(hop0 + h + lane);
-                    u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r; c.w = KMC_STREAM_HOP;
+                    u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r + p.rid_base; c.w = KMC_STREAM_HOP;
                     const u32x4 o = philox4x32_10(c, p.seed_lo, p.seed_hi);
                     rho_v = u53(o.x, o.y); u_v = u53_open0(o.z, o.w);
                 }

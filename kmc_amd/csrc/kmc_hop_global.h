@@ -39,6 +39,7 @@ struct HopGlobalParams {
     uint32_t seed_lo, seed_hi;
     double* time_total; double* step_time; double* gamma; long long* hist; long long* hops_done;
     long long* n_exact; int* status; double* barrier;
+    uint32_t rid_base;           // global id of replica 0 (see HopParams)
 };
 
 struct GbShared {
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(KMC_GB_THREADS) void hop_global_kernel(HopGlobalPar
             rho = dv.x; u = dv.y;
         } else {
             const unsigned long long hh = (unsigned long long)(hop0 + h);
-            u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r; c.w = KMC_STREAM_HOP;
+            u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r + p.rid_base; c.w = KMC_STREAM_HOP;
             const u32x4 o = philox4x32_10(c, p.seed_lo, p.seed_hi);
             rho = u53(o.x, o.y); u = u53_open0(o.z, o.w);
         }

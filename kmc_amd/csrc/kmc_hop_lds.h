@@ -67,6 +67,8 @@ struct HopParams {
     void* xscratch;              // [R][Q64_XSCRATCH] exact-path scratch of hop_q64_kernel
     const double* tcompact2;     // [3][2^15][2] pair tables (hop_q64_kernel<true>) or null
     int r_base;                  // replica of block 0 (a run may be launched as several groups)
+    uint32_t rid_base;           // global id of the context's replica 0 (kmc_set_replica_offset): the Philox counter
+                                 // word is rid_base + r, so an ensemble sharded over contexts / GPUs draws what one context would
 };
 
 // Profiling builds (-DKMC_STAMPS, scripts/stamps.py) time the segments of a hop with s_memtime.
@@ -250,7 +252,7 @@ static __device__ __forceinline__ void hop_lds_body(const HopParams& p, unsigned
                 rho_v = dv.x; u_v = dv.y;
             } else {
                 const unsigned long long hh = (unsigned long long)(hop0 + h0 + lane);
-                u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r; c.w = KMC_STREAM_HOP;
+                u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r + p.rid_base; c.w = KMC_STREAM_HOP;
                 const u32x4 o = philox4x32_10(c, p.seed_lo, p.seed_hi);
                 rho_v = u53(o.x, o.y); u_v = u53_open0(o.z, o.w);
             }

@@ -221,7 +221,7 @@ void hop_lds64_kernel(HopParams p)
                 rho_v = dv.x; u_v = dv.y;
             } else {
                 const unsigned long long hh = (unsigned long long)(hop0 + h0 + lane);
-                u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r; c.w = KMC_STREAM_HOP;
+                u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r + p.rid_base; c.w = KMC_STREAM_HOP;
                 const u32x4 o = philox4x32_10(c, p.seed_lo, p.seed_hi);
                 rho_v = u53(o.x, o.y); u_v = u53_open0(o.z, o.w);
             }

@@ -274,7 +274,7 @@ void hop_q64_kernel(HopParams p)
                     rho = dv.x; u = dv.y;
                 } else {
                     const unsigned long long hh = (unsigned long long)(hop0 + h0 + lane);
-                    u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r; c.w = KMC_STREAM_HOP;
+                    u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r + QP->rid_base; c.w = KMC_STREAM_HOP;
                     const u32x4 o = philox4x32_10(c, QP->seed_lo, QP->seed_hi);
                     rho = u53(o.x, o.y); u = u53_open0(o.z, o.w);
                 }

@@ -30,7 +30,7 @@ def _ptr(a, t):
 
 
 class KMCEngine:
-    def __init__(self, n_replicas, nx, ny=None, window_mode='hex_ref', device=0):
+    def __init__(self, n_replicas, nx, ny=None, window_mode='hex_ref', device=0, replica_offset=0):
         self._lib = _lib.load()
         self._ctx = C.c_void_p()
         ny = nx if ny is None else ny
@@ -42,6 +42,9 @@ class KMCEngine:
             raise KMCError(rc, msg)
         self.R, self.nx, self.ny, self.device = int(n_replicas), int(nx), int(ny), int(device)
         self.window_mode = window_mode
+        self.replica_offset = 0
+        if replica_offset:
+            self.set_replica_offset(replica_offset)
 
     # -- plumbing ----------------------------------------------------------
     def _chk(self, rc):
@@ -139,6 +142,12 @@ class KMCEngine:
         o = np.empty(self._shape(), dtype=np.int8)
         self._chk(self._lib.kmc_get_lattice(self._ctx, _ptr(o, C.c_int8)))
         return o
+
+    def set_replica_offset(self, offset):
+        """This engine's replica 0 is replica ``offset`` of a larger ensemble: the Philox streams of fill_random
+        and run are keyed by the global replica id, so the ensemble does not depend on how it is sharded."""
+        self._chk(self._lib.kmc_set_replica_offset(self._ctx, int(offset)))
+        self.replica_offset = int(offset)
 
     def fill_random(self, conc, seed):
         c = np.ascontiguousarray(np.broadcast_to(np.asarray(conc, dtype=np.float64), (self.R,)))

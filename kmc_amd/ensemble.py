@@ -13,20 +13,39 @@ ACC_FIELDS = ('count', 'sum_dstar', 'sum_dstar2', 'sum_dj', 'sum_dj2', 'sum_time
               'h0', 'h1', 'h2', 'h3', 'h4', 'h5')
 
 
-def shard_replicas(conc_points, replicas_per_point, rank=0, world=1):
-    """Concentration of every replica this rank owns.
+_M64 = (1 << 64) - 1
 
-    Each rank receives an equal share of EVERY concentration (hop rates vary by
-    orders of magnitude with x, so sharding by concentration would unbalance the
-    GPUs).  Returns (conc[R_local], point_index[R_local]).
+
+def derive_seed(seed, *tags):
+    """A 64-bit Philox key for (seed, tags...): splitmix64 over the tags, so that e.g. the seeds of lattice sizes
+    d and d + 1 are unrelated (seed + d would make (seed, d + 1) and (seed + 1, d) the same stream)."""
+    z = int(seed) & _M64
+    for t in tags:
+        z = (z + 0x9E3779B97F4A7C15 + ((int(t) & _M64) * 0xD1342543DE82EF95)) & _M64
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+        z ^= z >> 31
+    return z
+
+
+def shard_replicas(conc_points, replicas_per_point, rank=0, world=1):
+    """This rank's share of the ensemble: (conc[R_local], point_index[R_local], replica_offset).
+
+    The ensemble is ordered iteration-major: global replica g = k * n_points + p is averaging iteration k of
+    concentration p (the reference's loops hex_LiCoO2_kmc.py:686-693 with the inner one outermost).  Rank r owns
+    the iterations [r * K // world, (r + 1) * K // world) of EVERY concentration (hop rates vary by orders of
+    magnitude with x, so sharding by concentration would unbalance the GPUs): a contiguous range of global ids
+    starting at replica_offset, whatever the number of ranks, and K need not divide by it.  The Philox streams
+    are keyed by the global id (kmc_set_replica_offset), so the ensemble is the same at any GPU count.
     """
     conc_points = np.asarray(conc_points, dtype=np.float64)
-    if replicas_per_point % world:
-        raise ValueError('replicas per concentration (%d) must divide evenly over %d ranks'
-                         % (replicas_per_point, world))
-    per = replicas_per_point // world
-    idx = np.repeat(np.arange(conc_points.size), per)
-    return conc_points[idx], idx
+    if not (0 <= rank < world):
+        raise ValueError('rank %d outside world %d' % (rank, world))
+    k0, k1 = rank * replicas_per_point // world, (rank + 1) * replicas_per_point // world
+    if k1 == k0:
+        raise ValueError('rank %d of %d receives no replica of %d per concentration' % (rank, world, replicas_per_point))
+    idx = np.tile(np.arange(conc_points.size), k1 - k0)
+    return conc_points[idx], idx, k0 * conc_points.size
 
 
 def accumulate(point_index, n_points, dstar, dj, time, hops, hist):
@@ -85,25 +104,27 @@ def run_ensemble(engine_factory, nx, ny, conc_points, replicas_per_point, presim
     inject one); ``table`` = ('base', vec512, dumbbell) or ('dense', array).
     One "step" = int(nx*ny*x) hops (hex_LiCoO2_kmc.py:484); replicas of different
     concentration take different hop counts per step (kmc_run_counts).
+    The replicas are in shard_replicas' order (iteration-major: local replica l has concentration l % n_points).
     With ``return_replicas`` a third value holds THIS rank's per-replica numbers (conc, d_star, d_j,
     hist, barrier statistics) for the per-iteration lines of LiCoO2_kmc.out (kmc_amd.report).
     """
-    conc, point = shard_replicas(conc_points, replicas_per_point, rank, world)
+    conc, point, offset = shard_replicas(conc_points, replicas_per_point, rank, world)
     R = conc.size
     eng = engine_factory(R, nx, ny, window_mode, device)
     try:
+        eng.set_replica_offset(offset)
         if table[0] == 'base':
             from . import tables as _tables
             eng.set_base_table(table[1], table[2] if len(table) > 2 and table[2] is not None
                                else _tables.dumbbell_rate())
         else:
             eng.set_hex_table(table[1])
-        eng.fill_random(conc, seed + 7919 * rank)
+        eng.fill_random(conc, seed)                 # ONE seed for all ranks: streams are keyed by the global replica id
         eng.rates_full()
         hops_per_step = (nx * ny * 1 * conc).astype(np.int64)        # int(N*N*1*x), :484
-        eng.run_counts(hops_per_step * presim_steps, presim=True, seed=seed + 1 + rank)
+        eng.run_counts(hops_per_step * presim_steps, presim=True, seed=seed + 1)
         eng.init_displacements()
-        eng.run_counts(hops_per_step * sim_steps, presim=False, seed=seed + 1 + rank)
+        eng.run_counts(hops_per_step * sim_steps, presim=False, seed=seed + 1)
         st = eng.status()
         if st['status'].any():
             raise RuntimeError('replicas stopped early: status %r' % np.unique(st['status']))

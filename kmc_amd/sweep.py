@@ -40,7 +40,7 @@ def run_sweep(table, dimensions, concentrations, averaging_iterations, presimula
         for dimension in dimensions:
             results, _, local = ensemble.run_ensemble(
                 factory, dimension, dimension, concentrations, averaging_iterations, presimulation_iterations,
-                simulation_iterations, seed=seed + dimension, window_mode=window_mode, rank=rank, world=world,
+                simulation_iterations, seed=ensemble.derive_seed(seed, dimension), window_mode=window_mode, rank=rank, world=world,
                 device=device, table=table, reduce_device=reduce_device, return_replicas=True)
             all_results[dimension] = results
             if rank != 0:

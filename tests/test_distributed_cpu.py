@@ -19,7 +19,7 @@ WORKER = textwrap.dedent('''
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     points = [0.2, 0.5, 0.8]
-    conc, idx = ensemble.shard_replicas(points, 8, rank, world)
+    conc, idx, _ = ensemble.shard_replicas(points, 8, rank, world)
     rs = np.random.RandomState(100 + rank)            # stands in for this rank's device results
     ds, dj, t = rs.rand(conc.size), rs.rand(conc.size), rs.rand(conc.size)
     acc = ensemble.accumulate(idx, 3, ds, dj, t, np.full(conc.size, 10.0), np.ones((conc.size, 6)))
@@ -47,7 +47,7 @@ def test_two_rank_all_reduce(tmp_path):
     want = 0
     all_ds = {0: [], 1: [], 2: []}
     for rank in range(2):
-        conc, idx = ensemble.shard_replicas([0.2, 0.5, 0.8], 8, rank, 2)
+        conc, idx, _ = ensemble.shard_replicas([0.2, 0.5, 0.8], 8, rank, 2)
         rs = np.random.RandomState(100 + rank)
         ds, dj, t = rs.rand(conc.size), rs.rand(conc.size), rs.rand(conc.size)
         want = want + ensemble.accumulate(idx, 3, ds, dj, t, np.full(conc.size, 10.0), np.ones((conc.size, 6)))
@@ -72,12 +72,13 @@ SWEEP_WORKER = textwrap.dedent('''
         def __init__(self, R, nx, ny, wm, dev):
             self.R, self.n, self.hops = R, nx * ny, np.zeros(R, dtype=np.int64)
         def set_base_table(self, base, dumbbell): pass
+        def set_replica_offset(self, offset): self.offset = offset
         def fill_random(self, conc, seed): self.conc, self.seed = np.asarray(conc, dtype=float), seed
         def rates_full(self): pass
         def init_displacements(self): pass
         def run_counts(self, n, presim=False, seed=0): self.hops += np.asarray(n)
         def status(self): return dict(status=np.zeros(self.R, dtype=np.int32), hops_done=self.hops, n_exact=self.hops * 0)
-        def _v(self): return (1 + np.arange(self.R)) * self.conc * (1 + (self.seed %% 97))
+        def _v(self): return (1 + self.offset + np.arange(self.R)) * self.conc * (1 + (self.seed %% 97))
         def diffusion(self, conc): return self._v() * 1e-10, self._v() * 3e-10, np.zeros((self.R, 4))
         def scalars(self): return dict(time=self._v() * 1e-6, hist=np.tile(np.arange(6), (self.R, 1)) + self.hops[:, None])
         def barrier_stats(self): return dict(sum=self._v(), count=np.ones(self.R), min=self._v() * 0.5, max=self._v() * 2, last=self._v())
@@ -98,7 +99,7 @@ def test_two_rank_sweep_writes_files(tmp_path):
     """The driver script's loop (kmc_amd.sweep) over two gloo ranks with a stand-in engine: every rank takes half
     of each concentration's replicas, the means are over both, rank 0 writes the reference's result files."""
     import json
-    from kmc_amd import report
+    from kmc_amd import ensemble, report
     script = tmp_path / 'sweep_worker.py'
     script.write_text(SWEEP_WORKER)
     out_dir = tmp_path / 'out'
@@ -114,12 +115,10 @@ def test_two_rank_sweep_writes_files(tmp_path):
     row = 0
     for n in (8, 12):
         for k, x in enumerate((0.25, 0.5)):
-            # what the stand-in engines of both ranks produce for this point: 2 local replicas each
-            vals = []
-            for rank in range(2):
-                fill_seed = 5 + n + 7919 * rank
-                local_index = 2 * k + np.arange(2)                   # point-major within the rank
-                vals += ((1 + local_index) * x * (1 + fill_seed % 97)).tolist()
+            # what the stand-in engines of both ranks produce for this point: its 4 replicas are the global
+            # ids a * 2 + k (iteration-major), two per rank, ONE seed for both ranks
+            fill_seed = ensemble.derive_seed(5, n)
+            vals = ((1 + np.arange(4) * 2 + k) * x * (1 + fill_seed % 97)).tolist()
             r = res[str(n)][k]
             assert r['replicas'] == 4 and r['hops'] == 4 * 5 * int(n * n * x)
             np.testing.assert_allclose(r['d_star'], np.mean(vals) * 1e-10, rtol=1e-13)
@@ -127,3 +126,27 @@ def test_two_rank_sweep_writes_files(tmp_path):
             assert dat['Dimension'][row] == n and dat['Concentration'][row] == x and dat['D_star'][row] == r['d_star']
             np.testing.assert_allclose(kout['table'][row], [r['d_star'], x, r['error_star'], r['d_j'], r['error_j']], rtol=2e-8)
             row += 1
+
+
+def test_shard_replicas_is_a_partition_at_any_world_size():
+    """Global replica ids: iteration-major, contiguous per rank, the same ensemble for every number of ranks,
+    also when the replicas per concentration do not divide by it."""
+    from kmc_amd import ensemble
+    points = [0.1, 0.4, 0.7]
+    whole_c, whole_i, off = ensemble.shard_replicas(points, 10, 0, 1)
+    assert off == 0 and whole_c.size == 30 and np.array_equal(whole_i, np.tile(np.arange(3), 10))
+    for world in (2, 3, 4, 7, 8):
+        got_c, got_i, nxt = [], [], 0
+        for rank in range(world):
+            c, i, o = ensemble.shard_replicas(points, 10, rank, world)
+            assert o == nxt and c.size % 3 == 0            # contiguous, whole iterations
+            nxt = o + c.size
+            got_c.append(c)
+            got_i.append(i)
+        assert np.array_equal(np.concatenate(got_c), whole_c) and np.array_equal(np.concatenate(got_i), whole_i)
+    import pytest
+    with pytest.raises(ValueError):
+        ensemble.shard_replicas(points, 2, 2, 4)           # a rank without replicas
+    # seeds of neighbouring lattice sizes are unrelated (seed + dimension would collide with seed + 1, dimension - 1)
+    assert ensemble.derive_seed(5, 11) != ensemble.derive_seed(6, 10)
+    assert len({ensemble.derive_seed(s, d) for s in range(20) for d in range(20)}) == 400

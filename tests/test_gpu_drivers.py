@@ -104,7 +104,7 @@ def test_concentration_run(base512, dense):
 
 
 def test_sweep_writes_reference_files(base512, dense, tmp_path, capsys):
-    from kmc_amd import report, sweep
+    from kmc_amd import ensemble, report, sweep
     xs, avg, pre, sim, seed = [0.2, 0.5, 0.8], 3, 2, 3, 40
     res = sweep.run_sweep(('base', base512, None), [10, 16], xs, avg, pre, sim, seed=seed, out_dir=str(tmp_path))
     printed = capsys.readouterr().out
@@ -118,8 +118,9 @@ def test_sweep_writes_reference_files(base512, dense, tmp_path, capsys):
             n_li = int(n * n * 1 * x)
             ds, dj, tt, hist = [], [], [], np.zeros(6)
             for a in range(avg):
-                r = k * avg + a                          # rank 0 of 1: replica index = point-major
-                rep = _replay(dense, seed + n, seed + n + 1, r, n, x, pre * n_li, sim * n_li, 'hex_ref')
+                r = a * len(xs) + k                      # global replica id: iteration-major (ensemble.shard_replicas)
+                sd = ensemble.derive_seed(seed, n)
+                rep = _replay(dense, sd, sd + 1, r, n, x, pre * n_li, sim * n_li, 'hex_ref')
                 o = rep.diffusion(x)
                 ds.append(o[0])
                 dj.append(o[1])
@@ -144,7 +145,7 @@ def test_sweep_writes_reference_files(base512, dense, tmp_path, capsys):
 
 def test_temperature_sweep(tmp_path):
     """Next row 2: rates regenerated per kT on the device, then the same sweep."""
-    from kmc_amd import report, sweep
+    from kmc_amd import ensemble, report, sweep
     kts, n, x, avg, pre, sim = [0.02, 0.035], 12, 0.4, 2, 2, 3
     res = sweep.temperature_sweep(kts, [n], [x], avg, pre, sim, seed=7, out_dir=str(tmp_path), echo=False)
     n_li = int(n * n * 1 * x)
@@ -154,7 +155,8 @@ def test_temperature_sweep(tmp_path):
         dense_t = O.build_hex_table(base, O.dumbbell_rate(10 ** 13, kt))
         ds = []
         for r in range(avg):
-            rep = _replay(dense_t, 7 + n, 7 + n + 1, r, n, x, pre * n_li, sim * n_li, 'hex_ref')
+            sd = ensemble.derive_seed(7, n)
+            rep = _replay(dense_t, sd, sd + 1, r, n, x, pre * n_li, sim * n_li, 'hex_ref')
             ds.append(rep.diffusion(x)[0])
         got = res[kt][n][0]
         # the device's exp may differ from libm's in the last place: selections are the same unless a draw falls
@@ -164,3 +166,27 @@ def test_temperature_sweep(tmp_path):
         assert out['kb_t'] == kt and out['size'] == [n, n, 1]
         d_by_t.append(got['d_star'])
     assert d_by_t[1] > d_by_t[0]                           # hotter lattice diffuses faster
+
+
+def test_ensemble_is_the_same_at_any_rank_count(base512):
+    """One seed, Philox keyed by the global replica id: the ranks of a 2- or 3-rank job (run here one after the
+    other on the one GPU, their accumulators added as the all-reduce would) hold exactly the replicas of the
+    1-rank job -- per-replica D*, D_J, clocks and histograms bit for bit, 7 replicas per concentration (does not
+    divide by 2 or 3)."""
+    import kmc_amd
+    from kmc_amd import ensemble
+    xs, rpp, n = [0.3, 0.5, 0.8], 7, 64
+    factory = lambda R, nx, ny, wm, dev: kmc_amd.KMCEngine(R, nx, ny, wm, dev)    # noqa: E731
+    table = ('base', base512, None)
+    fin1, acc1, loc1 = ensemble.run_ensemble(factory, n, n, xs, rpp, 1, 2, seed=99, table=table, return_replicas=True)
+    for world in (2, 3):
+        acc, locs = 0, []
+        for rank in range(world):
+            _, a, loc = ensemble.run_ensemble(factory, n, n, xs, rpp, 1, 2, seed=99, table=table, rank=rank, world=world,
+                                              return_replicas=True)
+            acc = acc + a
+            locs.append(loc)
+        for key in ('conc', 'd_star', 'd_j', 'time', 'hist'):
+            assert np.array_equal(np.concatenate([l[key] for l in locs]), loc1[key]), key
+        assert np.array_equal(acc[:, [0, 6, 7, 8, 9, 10, 11, 12]], acc1[:, [0, 6, 7, 8, 9, 10, 11, 12]])   # counts: exact
+        np.testing.assert_allclose(acc, acc1, rtol=1e-13)                                                # sums: order of addition

@@ -635,11 +635,18 @@ def test_launch_group_controls_reject_bad_arguments(kmc, tables):
         eng.run(10, presim=True, seed=1)
         ms, groups = eng.run_span_ms(1)
         assert groups == 2 and ms > 0 and eng.last_kernel_ms() >= ms * 0.999
+        # the second group runs 400 x longer than the first: the time of the last launch is the span of BOTH
+        # groups (first start to last end), not the first group's kernel
+        eng.run_counts(np.array([10] * 8 + [4000] * 8), presim=True, seed=1)
+        span, groups = eng.run_span_ms(1)
+        g0 = eng.run_kernel_times(1)[-1]
+        assert groups == 2 and span > 5 * g0
+        assert eng.last_kernel_ms() >= span * 0.999
         with pytest.raises(kmc.engine.KMCError):
-            eng.run_span_ms(2)                              # more runs than there were
+            eng.run_span_ms(3)                              # more runs than there were
         with pytest.raises(kmc.engine.KMCError):
             eng.run_span_ms(65)
-        assert (eng.status()['hops_done'] == 10).all()
+        assert eng.status()['hops_done'].tolist() == [20] * 8 + [4010] * 8
 
 
 def test_any_size_kernel_two_builds_agree(kmc, tables, dense):
@@ -709,3 +716,33 @@ def test_checkpoint_resume_continues_bit_for_bit(kmc, tables, tmp_path, nx, ny, 
     with make_engine(kmc, tables, R + 1, nx, ny) as c:
         with np.load(path) as ck, pytest.raises(ValueError):
             c.restore(ck)
+
+
+@pytest.mark.parametrize('nx,ny,R,hops', [(64, 64, 24, 700), (30, 30, 24, 500), (70, 66, 6, 300), (4, 6, 6, 40)])
+def test_replica_offset_makes_sharding_invisible(kmc, tables, nx, ny, R, hops):
+    """kmc_set_replica_offset: two contexts of R/2 replicas with offsets 0 and R/2 reproduce one context of R bit
+    for bit -- random fill, Philox draws, every kernel family (16-per-CU 64 x 64, any-size LDS, large-lattice,
+    global-memory) -- so an ensemble does not depend on the number of GPUs it is sharded over."""
+    conc = np.linspace(0.3, 0.7, R)
+
+    def go(r0, r1, offset):
+        with make_engine(kmc, tables, r1 - r0, nx, ny) as eng:
+            eng.set_replica_offset(offset)
+            eng.fill_random(conc[r0:r1], 77)
+            occ0 = eng.get_lattice()
+            eng.rates_full()
+            eng.run(hops, presim=True, seed=78)
+            eng.init_displacements()
+            eng.run(hops, presim=False, seed=78)
+            sc = eng.scalars()
+            return occ0, eng.get_lattice(), eng.get_keys(), eng.get_displacements(), sc['time'], sc['hist'], sc['gamma']
+    whole = go(0, R, 0)
+    a, b = go(0, R // 2, 0), go(R // 2, R, R // 2)
+    for k, (w, x, y) in enumerate(zip(whole, a, b)):
+        assert np.array_equal(w, np.concatenate([x, y])), 'output %d differs' % k
+    # ... and the offset is what does it
+    c = go(R // 2, R, 0)
+    assert not np.array_equal(whole[0][R // 2:], c[0])
+    with make_engine(kmc, tables, 4, 8) as eng:
+        with pytest.raises(kmc.engine.KMCError):
+            eng.set_replica_offset(2 ** 32 - 2)

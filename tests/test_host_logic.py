@@ -87,10 +87,11 @@ def test_restricted_unpickler_refuses_code():
 
 
 def test_shard_and_statistics():
-    conc, idx = ensemble.shard_replicas([0.1, 0.5, 0.9], 512, rank=3, world=8)
-    assert conc.size == 3 * 64 and np.bincount(idx).tolist() == [64, 64, 64]
+    conc, idx, offset = ensemble.shard_replicas([0.1, 0.5, 0.9], 512, rank=3, world=8)
+    assert conc.size == 3 * 64 and np.bincount(idx).tolist() == [64, 64, 64] and offset == 3 * 64 * 3
+    assert ensemble.shard_replicas([0.1], 10, 0, 4)[0].size == 2 and ensemble.shard_replicas([0.1], 10, 1, 4)[0].size == 3
     with pytest.raises(ValueError):
-        ensemble.shard_replicas([0.1], 10, 0, 4)
+        ensemble.shard_replicas([0.1], 3, 0, 4)             # a rank without replicas
     rs = np.random.RandomState(0)
     ds, dj = rs.rand(192), rs.rand(192)
     acc = ensemble.accumulate(idx, 3, ds, dj, rs.rand(192), np.full(192, 100.0), np.ones((192, 6)))
