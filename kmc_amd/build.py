@@ -17,6 +17,20 @@ FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-fP
          '-Wno-unused-value', '-Wno-inline-asm', '-mllvm', '-enable-ipra=0']
 
 
+def source_sha256():
+    """Hash of everything the library is built from (sources, headers, flags): stands in for the commit id where
+    there is no .git (the GPU box), so that bench.py can tell whether a committed counter pass (profiles/) was
+    taken on the code it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(DEPS):
+        h.update(os.path.basename(d).encode() + b'\0')
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def hipcc():
     for cand in (shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
         if cand and os.path.exists(cand):
@@ -35,4 +49,7 @@ def build(force=False, verbose=False):
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv, verbose=True)
+    if '--source-sha256' in sys.argv:
+        print(source_sha256())
+    else:
+        build(force='--force' in sys.argv, verbose=True)

@@ -6,6 +6,8 @@ TAG=${1:-r1}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
+# what the counters are taken on: bench.py refuses a pass whose hash differs from the sources it is timing
+(cd $ROOT && python3 -m kmc_amd.build --source-sha256) > $OUT/source_sha256.txt
 cd /tmp
 export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline"

@@ -2,7 +2,8 @@
 """Condense gpurun_out/prof_<tag>/ (scripts/profile_bench.sh) into profiles/:
    <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
    <tag>_pmc.json           per-launch means of every counter for the dominant hop kernel
-   hbm_traffic.json         the HBM bytes per launch that bench.py reports as roofline.traffic
+   pmc_current.json         what bench.py's roofline reads: VALU-busy cycles, HBM bytes, instruction counts per launch,
+                            with the hash of the sources the pass was taken on
 usage: scripts/summarize_profile.py <tag> [kernel-substring]"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,7 +45,21 @@ if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
     for k, name in (('SQ_INSTS_VALU', 'valu_insts_per_launch'), ('SQ_INSTS_SALU', 'salu_insts_per_launch')):
         if k in c:
             hbm[name] = c[k]['mean_per_launch']              # bench.py's valu_issue figure
-    json.dump(hbm, open(os.path.join(dst, 'hbm_traffic.json'), 'w'), indent=1)
+    try:
+        hbm['source_sha256'] = open(os.path.join(src, 'source_sha256.txt')).read().strip()
+    except OSError:
+        hbm['source_sha256'] = None
+    out['source_sha256'] = hbm['source_sha256']
+    if 'SQ_ACTIVE_INST_VALU' in c:
+        hbm['active_inst_valu_per_launch'] = c['SQ_ACTIVE_INST_VALU']['mean_per_launch']       # quad-cycles, all waves
+        if 'SQ_WAVE_CYCLES' in c:
+            # fraction of a SIMD's cycles with the VALU busy while its 4 waves are resident
+            hbm['valu_busy_while_resident'] = 4 * c['SQ_ACTIVE_INST_VALU']['mean_per_launch'] / c['SQ_WAVE_CYCLES']['mean_per_launch']
+    if 'SQ_LDS_BANK_CONFLICT' in c and 'SQ_LDS_IDX_ACTIVE' in c:
+        hbm['lds_bank_conflict_frac'] = c['SQ_LDS_BANK_CONFLICT']['mean_per_launch'] / c['SQ_LDS_IDX_ACTIVE']['mean_per_launch']
+    if 'kernel_trace' in out:
+        hbm['kernel_avg_ms'] = out['kernel_trace']['avg_ms']
+    json.dump(hbm, open(os.path.join(dst, 'pmc_current.json'), 'w'), indent=1)
     out['hbm'] = hbm
 json.dump(out, open(os.path.join(dst, tag + '_pmc.json'), 'w'), indent=1)
 print(json.dumps(out, indent=1))
