@@ -13,7 +13,9 @@ pickle encoding), exec()s them and records inputs / outputs as neutral data.
 Outputs (all small):
     tests/golden/tables.npz          base-512 vectors, master table, sampled dense rows
     tests/golden/tables.json         hashes / known answers of the dense table
-    tests/golden/traj_*.npz          seeded trajectories of the functional hex path
+    tests/golden/traj_*.npz          seeded trajectories of the functional hex path; *_master: on the fold of the
+                                     master_dictionary.p restriction (BASELINE config 1); *_ooclass: the class's own
+                                     text (Mc_Lattice.py:60-232) on a lattice whose every site takes its border path
 """
 import argparse
 import hashlib
@@ -21,13 +23,16 @@ import itertools
 import json
 import math
 import os
-import pickle
+import random
 import sys
+import time
 
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+sys.path.insert(0, os.path.dirname(HERE))
+from kmc_amd.tables import load_table_pickle      # noqa: E402  (the restricted unpickler: executes nothing from the file)
 
 
 def ref_lines(ref, name, lo, hi):
@@ -37,10 +42,10 @@ def ref_lines(ref, name, lo, hi):
 
 
 def load_pickles(ref):
-    with open(os.path.join(ref, 'normcons_dictionary.p'), 'rb') as f:
-        normcons = pickle.load(f, encoding='latin1')
-    with open(os.path.join(ref, 'master_dictionary.p'), 'rb') as f:
-        master = pickle.load(f, encoding='latin1')
+    """Both pickles are plain dicts of str / int -> float; they are untrusted files, so they go through the
+    product's restricted unpickler (latin1, no globals allowed), never pickle.load."""
+    normcons = load_table_pickle(os.path.join(ref, 'normcons_dictionary.p'))
+    master = load_table_pickle(os.path.join(ref, 'master_dictionary.p'))
     return normcons, master
 
 
@@ -198,6 +203,87 @@ def run_scenario(g, nx, ny, conc, seed, n_presim, n_sim, oo_window=False):
         hist=np.array(g['hop_histogram']))
 
 
+def run_class_scenario(ref, g, hex_dict, nx, ny, conc, seed, n_presim, n_sim):
+    """The object-oriented path run from ITS OWN text: exec Mc_Lattice.py:60-232 (class mc_lattice through
+    calculate_diffusion_coefficients) and drive it as Mc_Lattice.py:248-257 does: fill_lattice, KMC_step x
+    n_presim, initialize_KMC, KMC_step x n_sim.  Patches: the class-level ``pickle.load(open("hex_dict.p"))``
+    takes the injected dict (the file is not in the reference), ``np.product`` (gone from numpy 2) is ``np.prod``.
+    nx must be <= 4: then every site satisfies the border test of :81 and takes the untransposed key path
+    :82-85; the interior fast path :95-100 reads the transposed neighbourhood and is out of contract.
+    Recorded in the functional fixtures' format; clocks are recomputed from the recorded (gamma, u) pairs with
+    the functional statements (:530-532, :754) because the class's own total_time is the defect B3."""
+    assert nx <= 4
+    src = ref_lines(ref, 'Mc_Lattice.py', 60, 232)
+    src = src.replace('pickle.load(open("hex_dict.p", "rb"))', 'INJECTED_HEX_DICT').replace('np.product', 'np.prod')
+    ns = dict(np=np, itertools=itertools, random=random, time=time, plt=None, INJECTED_HEX_DICT=hex_dict)
+    exec(compile(src, 'Mc_Lattice.py[60:232]', 'exec'), ns)
+    np.random.seed(seed)
+    random.seed(seed)
+    x = ns['mc_lattice']([nx, ny, 1])
+    x.fill_lattice(conc)
+    occ0 = (x.lattice[:, :, 0] == '1').astype(np.uint8)
+    P0 = np.array(x.probability_matrix[:, :, 0, :])
+    draws, idx, gammas = [], [], []
+    r_random, r_search, r_sum = random.random, np.searchsorted, np.sum
+
+    def rnd():
+        v = r_random()
+        draws.append(v)
+        return v
+
+    def search(*a, **k):
+        v = r_search(*a, **k)
+        idx.append(int(v))
+        return v
+
+    def sum_(*a, **k):
+        v = r_sum(*a, **k)
+        if np.ndim(v) == 0 and np.ndim(a[0]) == 4:
+            gammas.append(float(v))
+        return v
+    random.random, np.searchsorted, np.sum = rnd, search, sum_
+    try:
+        for _ in range(n_presim):
+            x.KMC_step()
+        x.initialize_KMC()
+        for _ in range(n_sim):
+            x.KMC_step()
+    finally:
+        random.random, np.searchsorted, np.sum = r_random, r_search, r_sum
+    n_li = x.number_of_li
+    assert n_li == int(nx * ny * conc) and len(idx) == (n_presim + n_sim) * n_li
+    # functional clock statements on the recorded pairs
+    npre = n_presim * n_li
+    u = np.array(draws[npre:]).reshape(n_sim * n_li, 2)[:, 1]
+    gs = np.array(gammas[npre:])
+    step_times, total_time = [], 0
+    for s_ in range(n_sim):
+        t = 0
+        for h in range(s_ * n_li, (s_ + 1) * n_li):
+            t += (-1. / gs[h]) * np.log(u[h])
+        step_times.append(float(t))
+        total_time = total_time + t
+    dist = np.array(x.distance_lattice)
+    size = [nx, ny, 1]
+    g['mc_lattice_size'] = size
+    d_star, dlist, d_j = g['get_diffusion_coefficient'](dist, size, total_time, g['lattice_constant'], conc)
+    dmat, dlist2, dj_len = g['get_distance'](dist, size, g['lattice_constant'])
+    P_final = np.array(x.probability_matrix[:, :, 0, :])
+    occ_final = (x.lattice[:, :, 0] == '1').astype(np.uint8)
+    fresh = np.zeros_like(P_final)
+    for i, j in itertools.product(range(nx), range(ny)):
+        fresh[i, j] = x.get_hex_probability([i, j, 0])
+    return dict(
+        nx=nx, ny=ny, conc=conc, seed=seed, n_presim=n_presim, n_sim=n_sim, oo_window=1, occ0=occ0, P0=P0,
+        draws=np.array(draws), idx=np.array(idx, dtype=np.int64), gammas=np.array(gammas), occ_final=occ_final,
+        tags_final=np.array(dist[:, :, 0, :], dtype=np.int64), P_final=P_final,
+        stale_mask=np.any(P_final != fresh, axis=-1), step_times=np.array(step_times), barriers=np.array([]),
+        total_time=float(total_time), d_star=float(d_star), d_j=float(d_j),
+        dist_matrix=dmat[:, :, 0], dist_list=np.array(dlist2), dj_len=float(dj_len), hist=np.array(x.hop_histogram),
+        class_clock=float(x.time_step_per_kmcstep),       # the class's running sum of every hop's dt (:175-176)
+        class_total_time=float(x.total_time), class_d_star=float('nan'), source='Mc_Lattice.py:60-232')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -266,11 +352,33 @@ def main():
         ('n30_x05', 30, 30, 0.5, 2024, 2, 3, False),
         ('n16_x03_oo', 16, 16, 0.3, 5, 2, 4, True),
     ]
-    for name, nx, ny, conc, seed, npre, nsim, oo in scenarios:
-        out = run_scenario(g, nx, ny, conc, seed, npre, nsim, oo)
+    def emit(name, out, table):
+        out['table'] = table                         # which base table the dense table was folded from
         np.savez_compressed(os.path.join(GOLDEN, 'traj_%s.npz' % name), **out)
         print(name, 'hops', out['idx'].size, 'stale', int(out['stale_mask'].sum()),
               'D*', out['d_star'], 'DJ', out['d_j'], 'hist', out['hist'])
+
+    for name, nx, ny, conc, seed, npre, nsim, oo in scenarios:
+        emit(name, run_scenario(g, nx, ny, conc, seed, npre, nsim, oo), 'normcons')
+    # BASELINE's headline lattice: 6n = 24 576 entries, np.sum crosses three 8192-element buffers (:486)
+    emit('n64_x05', run_scenario(g, 64, 64, 0.5, 64064, 1, 1, False), 'normcons')
+    # the class's own hop / refresh / fill text; nx = 4: every site on the border path (see run_class_scenario)
+    emit('n4x12_x05_ooclass', run_class_scenario(args.ref, g, hex_dict, 4, 12, 0.5, 412, 3, 6), 'normcons')
+    # BASELINE config 1 as written: 30 x 30, x = 0.5, the table of master_dictionary.p.  The reference's builder
+    # text folds the master values of the 512 keys the builder uses (sites 2, 3, 7, 12 = Li), rates 7.5e-13 .. 9.8e7
+    master512 = {key: master[int(key.replace('0', '3'))] for key in normcons}
+    hex_master, _ = build_reference_hex_dict(args.ref, master512)
+    gm = reference_namespace(args.ref, hex_master)
+    emit('n30_x05_master', run_scenario(gm, 30, 30, 0.5, 30305, 2, 3, False), 'master')
+    emit('n10_x03_master', run_scenario(gm, 10, 10, 0.3, 10103, 3, 5, False), 'master')
+    # beyond 64 x 64 (the large-lattice and global-memory kernels), rectangular, 27 720 entries: four np.sum buffers
+    emit('n70x66_x04_master', run_scenario(gm, 70, 66, 0.4, 7066, 1, 1, False), 'master')
+    dm = np.zeros((1 << 18, 6))
+    for key, val in hex_master.items():
+        dm[int(key, 2)] = val
+    info['dense_master_sha256'] = hashlib.sha256(dm.astype('<f8').tobytes()).hexdigest()
+    with open(os.path.join(GOLDEN, 'tables.json'), 'w') as f:
+        json.dump(info, f, indent=1)
 
 
 if __name__ == '__main__':

@@ -42,9 +42,14 @@ def dense(tables):
     return O.build_hex_table(tables[0]['base512_normcons'])
 
 
-def make_engine(kmc, tables, R, nx, ny=None, mode='hex_ref'):
+@pytest.fixture(scope='module')
+def dense_master(tables):
+    return O.build_hex_table(tables[0]['base512_master'])
+
+
+def make_engine(kmc, tables, R, nx, ny=None, mode='hex_ref', table='normcons'):
     eng = kmc.KMCEngine(R, nx, ny, window_mode=mode)
-    eng.set_base_table(tables[0]['base512_normcons'], kmc.tables.dumbbell_rate())
+    eng.set_base_table(tables[0]['base512_' + table], kmc.tables.dumbbell_rate())
     return eng
 
 
@@ -143,12 +148,18 @@ def _split_draws(g):
 
 @pytest.mark.parametrize('force_exact', [False, True], ids=['certified', 'exact'])
 @pytest.mark.parametrize('path', TRAJ, ids=[os.path.basename(p)[5:-4] for p in TRAJ])
-def test_golden_trajectory(kmc, tables, dense, path, force_exact):
+def test_golden_trajectory(kmc, tables, dense, dense_master, path, force_exact):
+    """Every trajectory generated by the reference's own text: the functional path on the normcons fold (10 x 10 ...
+    64 x 64, where np.sum crosses three buffers), on the master_dictionary.p fold (BASELINE config 1: rates over 20
+    decades), the hybrid OO-window scenario and the class's own text (Mc_Lattice.py:60-232)."""
     g = np.load(path)
     nx, ny, conc = int(g['nx']), int(g['ny']), float(g['conc'])
     mode = 'obj_ref' if int(g['oo_window']) else 'hex_ref'
     n_hops, d_pre, d_sim = _split_draws(g)
-    with make_engine(kmc, tables, 1, nx, ny, mode) as eng:
+    table = str(g['table'])
+    if table == 'master':
+        dense = dense_master
+    with make_engine(kmc, tables, 1, nx, ny, mode, table) as eng:
         eng.set_debug(force_exact=force_exact)
         eng.set_lattice(g['occ0'][None])
         eng.rates_full()
@@ -186,6 +197,36 @@ def test_golden_trajectory(kmc, tables, dense, path, force_exact):
         stale = np.any(eng.get_rates()[0] != O.rates_full(g['occ_final'], dense), axis=-1)
         assert np.array_equal(stale, g['stale_mask'])
         np.testing.assert_allclose(sc['gamma'][0], np.sum(g['P_final']), rtol=RTOL)
+
+
+@pytest.mark.parametrize('force_exact', [False, True], ids=['certified', 'exact'])
+@pytest.mark.parametrize('name,which', [('n64_x05', 1), ('n64_x05', 2), ('n64_x05', 3), ('n30_x05_master', 1),
+                                        ('n70x66_x04_master', 0), ('n70x66_x04_master', 1)],
+                         ids=['n64-generic', 'n64-lds64', 'n64-q64', 'n30master-generic', 'n70x66master-big', 'n70x66master-global'])
+def test_reference_trajectory_every_kernel_family(kmc, tables, dense, dense_master, name, which, force_exact):
+    """The reference-generated trajectories at BASELINE's lattice sizes through EVERY hop kernel that can take them
+    (kmc_set_hop_kernel), certified and with every hop forced through the exact replay: selections, lattice, tags,
+    rate matrix bit for bit; clocks to 1e-12."""
+    g = np.load(os.path.join(GOLDEN, 'traj_%s.npz' % name))
+    nx, ny, conc = int(g['nx']), int(g['ny']), float(g['conc'])
+    n_hops, d_pre, d_sim = _split_draws(g)
+    with make_engine(kmc, tables, 1, nx, ny, 'hex_ref', str(g['table'])) as eng:
+        eng.set_hop_kernel(which=which)
+        eng.set_debug(force_exact=force_exact)
+        eng.set_lattice(g['occ0'][None])
+        eng.rates_full()
+        idx1 = eng.run(len(d_pre), presim=True, draws=d_pre[None], want_trace=True)
+        eng.init_displacements()
+        idx2 = eng.run(len(d_sim), presim=False, draws=d_sim[None], want_trace=True)
+        assert np.array_equal(np.concatenate([idx1[0], idx2[0]]), g['idx'])
+        assert np.array_equal(eng.get_lattice()[0], g['occ_final'])
+        assert np.array_equal(eng.get_reference_tags()[0], g['tags_final'])
+        assert np.array_equal(eng.get_rates()[0], g['P_final'])
+        np.testing.assert_allclose(eng.scalars()['time'][0], float(g['total_time']), rtol=RTOL)
+        np.testing.assert_allclose(eng.gamma_exact()[0], np.sum(g['P_final']), rtol=0)     # np.sum's own bits (row S1)
+        ds, dj, _ = eng.diffusion(conc)
+        np.testing.assert_allclose([ds[0], dj[0]], [float(g['d_star']), float(g['d_j'])], rtol=RTOL)
+        assert eng.status()['n_exact'][0] == (g['idx'].size if force_exact else 0)
 
 
 # ---------------------------------------------------------------- hop loop vs C oracle
@@ -556,7 +597,7 @@ def test_per_replica_hop_counts(kmc, tables, nx, ny):
 
 
 @pytest.mark.gpu
-def test_full_size_ensemble_two_kernels(kmc, tables):
+def test_full_size_ensemble_two_kernels(kmc, tables, dense):
     """BASELINE's headline size -- 4096 replicas of 64 x 64, the bench configuration, one full round of
     16 workgroups per CU -- through the default 16-per-CU kernel and through the 8-per-CU kernel:
     every lattice, key, displacement tag and histogram identical, clocks equal to rounding, nobody
@@ -583,6 +624,17 @@ def test_full_size_ensemble_two_kernels(kmc, tables):
     np.testing.assert_allclose(a[7], b[7], rtol=1e-13)
     # conservation: hops move atoms, they never create or destroy them
     assert np.array_equal(a[0].reshape(R, -1).sum(axis=1), (a[2].reshape(R, -1, 4)[:, :, 0] >= 0).sum(axis=1))
+    # ... and the oracle at this size: three replicas (first, middle, last) replayed from the same Philox streams
+    for r in (0, 2047, 4095):
+        rep = CO.Replica(PH.fill_lattice(31, r, 64, 64, conc[r]), dense)
+        rep.run(PH.hop_draws(seed, r, 0, hp), True, want_trace=False)
+        rep.init_tags()
+        rep.run(PH.hop_draws(seed + 1, r, hp, hs), False, want_trace=False)
+        assert np.array_equal(a[0][r], rep.occ)
+        t = a[2][r].astype(np.int64)
+        assert np.array_equal(np.stack([t[..., 0], t[..., 1], 100 * t[..., 2] + t[..., 3]], axis=-1), rep.tags)
+        assert np.array_equal(a[3][r], rep.hist.astype(np.int64))
+        np.testing.assert_allclose(a[6][r], rep.time.value, rtol=RTOL)
 
 
 # ---------------------------------------------------------------- launch groups

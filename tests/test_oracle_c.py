@@ -31,9 +31,17 @@ def test_numpy_sum():
         assert CO.numpy_sum(a) == float(np.sum(a.reshape(-1, 1, 1, 1))), n
 
 
+@pytest.fixture(scope='module')
+def dense_master():
+    t = np.load(os.path.join(GOLDEN, 'tables.npz'))
+    return O.build_hex_table(t['base512_master'])
+
+
 @pytest.mark.parametrize('path', TRAJ, ids=[os.path.basename(p)[5:-4] for p in TRAJ])
-def test_trajectory(path, dense):
+def test_trajectory(path, dense, dense_master):
     g = np.load(path)
+    if str(g['table']) == 'master':
+        dense = dense_master
     conc = float(g['conc'])
     mode = 'obj_ref' if int(g['oo_window']) else 'hex_ref'
     rep = CO.Replica(g['occ0'], dense, mode)

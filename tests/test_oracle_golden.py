@@ -72,9 +72,20 @@ def test_excited_energy_guards():
         O.excited_energy('1111111110111111')
 
 
+@pytest.fixture(scope='module')
+def dense_master(tables):
+    """The fold of master_dictionary.p's restriction to the builder's 512 keys (BASELINE config 1's table)."""
+    t, info = tables
+    d = O.build_hex_table(t['base512_master'])
+    assert hashlib.sha256(d.astype('<f8').tobytes()).hexdigest() == info['dense_master_sha256']
+    return d
+
+
 @pytest.mark.parametrize('path', TRAJ, ids=[os.path.basename(p)[5:-4] for p in TRAJ])
-def test_trajectory(path, dense):
+def test_trajectory(path, dense, dense_master):
     g = np.load(path)
+    if str(g['table']) == 'master':
+        dense = dense_master
     nx, ny, conc = int(g['nx']), int(g['ny']), float(g['conc'])
     mode = 'obj_ref' if int(g['oo_window']) else 'hex_ref'
     occ = g['occ0'].copy()
@@ -95,6 +106,10 @@ def test_trajectory(path, dense):
         assert res['barrier'] == g['barriers'][-1]
     stale = np.any(res['P'] != O.rates_full(res['occ'], dense), axis=-1)
     assert np.array_equal(stale, g['stale_mask'])
+    if 'class_clock' in g.files:
+        # the class's text (Mc_Lattice.py:175-176) adds every hop's dt into one running sum; the functional
+        # statements sum per step: the same numbers in another order
+        np.testing.assert_allclose(res['total_time'], float(g['class_clock']), rtol=1e-13)
     mat, lst, dj = O.get_distance(res['tags'], [nx, ny, 1])
     assert np.array_equal(mat, g['dist_matrix'])
     assert np.array_equal(lst, g['dist_list'])
