@@ -217,7 +217,13 @@ def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red
     for _ in range(args.warmup):
         eng.run(hops_per_step, presim=False, seed=SEED)
     eng.diffusion(CONC)              # warm-up of the exchange step too (first call loads its kernel)
-    ensemble.all_reduce_acc(np.zeros((1, len(ensemble.ACC_FIELDS))), red_dev)   # ... and of the collective (RCCL set-up)
+    rccl = None
+    if args.collective == 'rccl' and dist is not None:
+        # the engine's own communicator: rank 0 makes the id, torch.distributed only carries its 128 bytes
+        box = [kmc_amd.KMCEngine.comm_unique_id() if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0, device=red_dev)
+        rccl = (eng, eng.comm_create(box[0], dist.get_world_size(), dist.get_rank()))
+    ensemble.all_reduce_acc(np.zeros((1, len(ensemble.ACC_FIELDS))), red_dev, rccl)   # ... and of the collective (RCCL set-up)
     eng.sync()
 
     def barrier():
@@ -237,7 +243,7 @@ def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red
     st = eng.status()
     acc = ensemble.accumulate(np.zeros(R, dtype=np.int64), 1, ds, dj, sc['time'],
                               st['hops_done'].astype(np.float64), sc['hist'].astype(np.float64))
-    acc = ensemble.all_reduce_acc(acc, red_dev)
+    acc = ensemble.all_reduce_acc(acc, red_dev, rccl)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -258,6 +264,8 @@ def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red
                n_exact=int(st['n_exact'].sum()), stopped=int((st['status'] != 0).sum()),
                stats=ensemble.finalize(acc, [CONC])[0], fold_ms=fold_ms, rates_ms=rates_ms, check=check,
                hops_per_step=hops_per_step, base512=base512)
+    if rccl is not None:
+        eng.comm_destroy(rccl[1])
     eng.close()
     return out
 
@@ -274,6 +282,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--replicas', type=int, default=ENSEMBLE, help='replicas per GPU (weak) / in total (strong)')
+    ap.add_argument('--collective', choices=('torch', 'rccl'), default='torch',
+                    help='transport of the one all-reduce: torch.distributed (backend nccl = RCCL), or kmc_allreduce_stats '
+                         '(an RCCL communicator of the engine\'s own, behind the C ABI)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -372,7 +383,8 @@ def main():
                                % (args.replicas, 'per GPU' if args.scaling == 'weak' else 'in total', args.scaling, total, world),
                    'replicas_total': total, 'replicas_rank0': R, 'lattice': [N_SIDE, N_SIDE], 'concentration': CONC,
                    'hops_per_step': hops_per_step, 'seed': SEED,
-                   'parallelism': 'replicas sharded over %d GPU(s), no data-path collective, one all-reduce of D* accumulators' % world},
+                   'parallelism': 'replicas sharded over %d GPU(s), no data-path collective, one all-reduce of D* accumulators (%s)'
+                                  % (world, 'torch.distributed' if args.collective == 'torch' or world == 1 else 'kmc_allreduce_stats: RCCL behind the C ABI')},
         'roofline': roof,
         'kernel_hops_per_s': step_hops / (k_ms * 1e-3),
         'exact_path_hops': m['n_exact'], 'stopped_replicas': m['stopped'],

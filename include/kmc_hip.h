@@ -170,6 +170,22 @@ int kmc_diffusion(kmc_ctx* ctx, const double* conc /* [R] */, double lattice_con
 int kmc_diffusion_noalloc(kmc_ctx* ctx, const double* conc_dev, double lattice_constant,
                           double* dstar_dev, double* dj_dev, double* msd_dev);
 
+/* ---- the one collective (multi-GPU ensembles) --------------------------------------------------------
+ * Replicas (the loops hex_LiCoO2_kmc.py:679-693) are sharded over one context per GPU, one process per GPU; the
+ * only exchange is the sum of the per-concentration accumulators behind the reference's mean and np.std
+ * (:783-786).  kmc_allreduce_stats sums acc[0 .. n) (host, in place) over the ranks of an RCCL communicator with ONE
+ * ncclAllReduce(sum, f64) on the context's stream.  The communicator is the caller's (any ncclComm_t whose device is
+ * the context's), or is made here: rank 0 calls kmc_comm_unique_id, the 128 bytes reach the other ranks by the
+ * host's own means (torch.distributed broadcast, MPI, a file), every rank calls kmc_comm_create (collective: it
+ * returns when all nranks have called).  RCCL is opened with dlopen on first use: the librccl.so.1 of the ROCm this
+ * library is linked to (the stream handed to it is this library's HIP runtime's), so a communicator made elsewhere
+ * must come from that same copy -- torch's own communicators (torch ships its own RCCL and HIP runtime) are not
+ * usable here.  No counterpart in the reference, which is single-process. */
+int kmc_comm_unique_id(void* id128 /* 128 bytes out */);
+int kmc_comm_create(kmc_ctx* ctx, const void* id128, int nranks, int rank, void** comm_out);
+int kmc_comm_destroy(kmc_ctx* ctx, void* comm);
+int kmc_allreduce_stats(kmc_ctx* ctx, void* rccl_comm, double* acc, int n);
+
 /* get_distance, hex_LiCoO2_kmc.py:558-586: distances_travelled_matrix * a per site
  * (0 where vacant); the list and the vector sum follow from it and msd_out. */
 int kmc_get_distances(kmc_ctx* ctx, double lattice_constant, double* matrix /* [R][nx][ny] */);

@@ -69,7 +69,8 @@ class mc_lattice:
     def _engine(self):
         if self._eng is None:
             if type(self).rate_table is None:
-                raise RuntimeError('no rate table: call mc_lattice.set_rate_table(...) first')
+                # the reference's class body loads hex_dict.p from the working directory (Mc_Lattice.py:64)
+                type(self).set_rate_table(_tables.find_default_table('.'))
             kind, arr, dumbbell = type(self).rate_table
             self._eng = _engine.KMCEngine(1, self.dimensions[0], self.dimensions[1],
                                           window_mode=self.window_mode, device=self.device)

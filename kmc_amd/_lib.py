@@ -55,6 +55,10 @@ SIGNATURES = {
     'kmc_set_debug': (C.c_int, [_ctx, C.c_int, C.c_double]),
     'kmc_diffusion': (C.c_int, [_ctx, _dp, C.c_double, _dp, _dp, _dp]),
     'kmc_diffusion_noalloc': (C.c_int, [_ctx, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'kmc_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'kmc_comm_create': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    'kmc_comm_destroy': (C.c_int, [_ctx, C.c_void_p]),
+    'kmc_allreduce_stats': (C.c_int, [_ctx, C.c_void_p, _dp, C.c_int]),
     'kmc_get_distances': (C.c_int, [_ctx, C.c_double, _dp]),
     'kmc_uses_lds_path': (C.c_int, [_ctx]),
     'kmc_lds_bytes': (C.c_int, [_ctx]),

@@ -5,6 +5,8 @@
 // Entry points are declared in include/kmc_hip.h with the reference lines each
 // one replaces.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types and enums only: the library itself is opened at run time (rccl_api)
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -81,6 +83,7 @@ struct kmc_ctx {
     int force_exact;
     double margin_scale;
     uint32_t rid_base;     // kmc_set_replica_offset: global id of replica 0 (Philox counter word)
+    double* coll_buf; size_t coll_cap;   // device staging of kmc_allreduce_stats (pooled)
     char err[512];
 };
 
@@ -616,7 +619,8 @@ int kmc_destroy(kmc_ctx* c)
     for (int g = 0; g < KMC_GROUPS; ++g) if (c->gstream[g]) hipStreamSynchronize(c->gstream[g]);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* bufs[] = {c->occ, c->keys, c->tags, c->table, c->wsum, c->time_total, c->step_time, c->gamma, c->hist,
-                    c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel, c->w_g, c->tcompact, c->tcompact2, c->hier, c->xscratch};
+                    c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel, c->w_g, c->tcompact, c->tcompact2, c->hier, c->xscratch,
+                    c->coll_buf};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -1361,6 +1365,117 @@ int kmc_diffusion_noalloc(kmc_ctx* c, const double* conc_dev, double a, double* 
     diffusion_finalize_kernel<<<(c->R + 255) / 256, 256, 0, c->stream>>>(part, c->time_total, conc_dev, c->R, c->nx, c->ny, a,
                                                                          dstar_dev, dj_dev, msd_dev);
     HIPCHK(c, hipGetLastError());
+    return KMC_OK;
+}
+
+// ---------------------------------------------------------------- the one collective
+// RCCL is opened at run time, so that a process that never reduces across GPUs (one GPU, or torch.distributed as
+// the transport) does not load the 570 MB library.  It must be the copy built against THIS library's HIP runtime
+// (the engine's stream is handed to it): the librccl.so.1 that lies beside the libamdhip64 we are linked to --
+// not whichever copy the process may hold already (torch ships its own RCCL over its own HIP runtime) -- and it is
+// opened RTLD_LOCAL, so that the two copies never see each other's symbols.
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*);
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    const char* (*GetErrorString)(ncclResult_t);
+    char err[256];
+    bool tried, ok;
+};
+static RcclApi g_rccl;
+
+static const RcclApi* rccl_api()
+{
+    RcclApi& a = g_rccl;
+    if (a.tried) return a.ok ? &a : nullptr;
+    a.tried = true;
+    void* h = nullptr;
+    Dl_info info;
+    char path[4096];
+    if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+        const char* slash = strrchr(info.dli_fname, '/');
+        if (slash && (size_t)(slash - info.dli_fname) + 32 < sizeof path) {
+            const size_t dir = (size_t)(slash - info.dli_fname) + 1;
+            memcpy(path, info.dli_fname, dir);
+            strcpy(path + dir, "librccl.so.1");
+            h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        }
+    }
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) { snprintf(a.err, sizeof a.err, "cannot open the librccl.so.1 of this library's ROCm: %s", dlerror()); return nullptr; }
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
+    if (!a.ok) snprintf(a.err, sizeof a.err, "librccl lacks one of ncclGetUniqueId / CommInitRank / CommDestroy / AllReduce");
+    return a.ok ? &a : nullptr;
+}
+
+#define RCCLCHK(ctx, api, call)                                                                 \
+    do {                                                                                        \
+        ncclResult_t r_ = (call);                                                               \
+        if (r_ != ncclSuccess) return fail(ctx, KMC_EHIP, "%s failed: %s", #call, (api)->GetErrorString(r_)); \
+    } while (0)
+
+int kmc_comm_unique_id(void* id128)
+{
+    if (!id128) return fail(nullptr, KMC_EINVAL, "kmc_comm_unique_id: null pointer");
+    const RcclApi* a = rccl_api();
+    if (!a) return fail(nullptr, KMC_EHIP, "kmc_comm_unique_id: %s", g_rccl.err);
+    ncclUniqueId id;
+    RCCLCHK(nullptr, a, a->GetUniqueId(&id));
+    memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return KMC_OK;
+}
+
+int kmc_comm_create(kmc_ctx* c, const void* id128, int nranks, int rank, void** comm_out)
+{
+    CTXCHK(c);
+    if (!id128 || !comm_out || nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(c, KMC_EINVAL, "kmc_comm_create: need an id, 0 <= rank < nranks");
+    const RcclApi* a = rccl_api();
+    if (!a) return fail(c, KMC_EHIP, "kmc_comm_create: %s", g_rccl.err);
+    ncclUniqueId id;
+    memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    RCCLCHK(c, a, a->CommInitRank(&comm, nranks, id, rank));      // binds the communicator to the context's device (current)
+    *comm_out = comm;
+    return KMC_OK;
+}
+
+int kmc_comm_destroy(kmc_ctx* c, void* comm)
+{
+    CTXCHK(c);
+    if (!comm) return KMC_OK;
+    const RcclApi* a = rccl_api();
+    if (!a) return fail(c, KMC_EHIP, "kmc_comm_destroy: %s", g_rccl.err);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    RCCLCHK(c, a, a->CommDestroy((ncclComm_t)comm));
+    return KMC_OK;
+}
+
+// Sum of acc[0 .. n) over the ranks of rccl_comm, in place: the mean / np.std accumulators of the ensemble loop
+// (hex_LiCoO2_kmc.py:783-786).  One ncclAllReduce(sum, f64) on the context's stream; ~1 KB, latency bound.
+int kmc_allreduce_stats(kmc_ctx* c, void* rccl_comm, double* acc, int n)
+{
+    CTXCHK(c);
+    if (!rccl_comm || !acc || n < 1 || n > (1 << 24)) return fail(c, KMC_EINVAL, "kmc_allreduce_stats: need a communicator, a buffer and 1 <= n <= 2^24");
+    const RcclApi* a = rccl_api();
+    if (!a) return fail(c, KMC_EHIP, "kmc_allreduce_stats: %s", g_rccl.err);
+    if (c->coll_cap < (size_t)n) {
+        if (c->coll_buf) HIPCHK(c, hipFree(c->coll_buf));
+        c->coll_buf = nullptr; c->coll_cap = 0;
+        const size_t cap = (size_t)n < 4096 ? 4096 : (size_t)n;
+        HIPCHK(c, hipMalloc((void**)&c->coll_buf, cap * 8));
+        c->coll_cap = cap;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->coll_buf, acc, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    RCCLCHK(c, a, a->AllReduce(c->coll_buf, c->coll_buf, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)rccl_comm, c->stream));
+    HIPCHK(c, hipMemcpyAsync(acc, c->coll_buf, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return KMC_OK;
 }
 

@@ -308,6 +308,34 @@ class KMCEngine:
                                                   C.c_void_p(int(dstar_dev)), C.c_void_p(int(dj_dev)),
                                                   C.c_void_p(int(msd_dev)) if msd_dev else None))
 
+    # -- the one collective ----------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes from ncclGetUniqueId (rank 0 calls this and hands them to the other ranks)."""
+        buf = C.create_string_buffer(128)
+        lib = _lib.load()
+        rc = lib.kmc_comm_unique_id(buf)
+        if rc != 0:
+            raise KMCError(rc, lib.kmc_last_error(None).decode())
+        return buf.raw
+
+    def comm_create(self, unique_id, nranks, rank):
+        """RCCL communicator of this engine's GPU (collective over the nranks callers); an opaque handle."""
+        if len(unique_id) != 128:
+            raise ValueError('unique id must be 128 bytes')
+        comm = C.c_void_p()
+        self._chk(self._lib.kmc_comm_create(self._ctx, C.c_char_p(bytes(unique_id)), int(nranks), int(rank), C.byref(comm)))
+        return comm
+
+    def comm_destroy(self, comm):
+        self._chk(self._lib.kmc_comm_destroy(self._ctx, comm))
+
+    def allreduce_stats(self, comm, acc):
+        """Sum ``acc`` (float64 array) over the ranks of ``comm`` with one RCCL all-reduce on this engine's stream."""
+        a = np.ascontiguousarray(acc, dtype=np.float64).copy()
+        self._chk(self._lib.kmc_allreduce_stats(self._ctx, comm, _ptr(a, C.c_double), int(a.size)))
+        return a
+
     def distances(self, lattice_constant=LATTICE_CONSTANT):
         """distances_travelled_matrix * a (hex_LiCoO2_kmc.py:577-578), (R, nx, ny)."""
         m = np.empty(self._shape(), dtype=np.float64)

@@ -64,9 +64,13 @@ def accumulate(point_index, n_points, dstar, dj, time, hops, hist):
     return acc
 
 
-def all_reduce_acc(acc, device=None):
-    """Sum the accumulators over all ranks (no-op without a process group)."""
+def all_reduce_acc(acc, device=None, rccl=None):
+    """Sum the accumulators over all ranks (no-op without a process group).  ``rccl`` = (engine, communicator)
+    sends them through the C ABI instead (kmc_allreduce_stats: one ncclAllReduce on the engine's stream)."""
     import sys
+    if rccl is not None:
+        eng, comm = rccl
+        return eng.allreduce_stats(comm, acc).reshape(np.shape(acc))
     if 'torch' not in sys.modules:           # no process group can exist: single rank
         return acc
     import torch.distributed as dist

@@ -7,7 +7,10 @@ the C-ABI engine (no CPU fallback).  Reference lines are cited per function.
 Typical use mirrors hex_LiCoO2_kmc.py:695-768::
 
     import kmc_amd.hex_LiCoO2_kmc as kmc
-    kmc.set_rate_table('master_dictionary.p')        # or normcons_dictionary.p / hex_dict.p
+    kmc.set_rate_table('master_dictionary.p')        # or normcons_dictionary.p / hex_dict.p; without this call the
+                                                     # first use loads hex_dict.p (else normcons_dictionary.p, else
+                                                     # master_dictionary.p) from the working directory, as the
+                                                     # reference does at import (:636, :644)
     kmc.mc_lattice_size = [30, 30, 1]; kmc.Li_concentration = 0.5
     kmc.mc_lattice = lattice                         # float array of -1 (Li) / +1 (Vac)
     P = kmc.kmc_evolve(lattice, P, 0, 0, True)
@@ -72,7 +75,8 @@ def set_rate_table(source, dumbbell=None):
 
 def _engine_for(nx, ny):
     if _table is None:
-        raise RuntimeError('no rate table: call kmc_amd.hex_LiCoO2_kmc.set_rate_table(...) first')
+        # the reference loads hex_dict.p from the working directory when it is imported (:636, :644)
+        set_rate_table(_tables.find_default_table('.'))
     key = (int(nx), int(ny), window_mode, device)
     eng = _engines.get(key)
     if eng is None:

@@ -117,6 +117,25 @@ def load_any(path):
     return 'base', base512_from_dict(d)
 
 
+DEFAULT_TABLE_FILES = ('hex_dict.p', 'normcons_dictionary.p', 'master_dictionary.p')
+
+
+def find_default_table(directory='.'):
+    """The table a reference script would have loaded by itself, looked up in ``directory`` (the working
+    directory): ``hex_dict.p`` (read at import by hex_LiCoO2_kmc.py:636 / :644 and in the class body,
+    Mc_Lattice.py:64), else ``normcons_dictionary.p`` (what hex_dict_builder.py:20 folds into it), else
+    ``master_dictionary.p`` (LiCoO2_kmc.py:491; the table BASELINE's north star names).  Returns the path; raises
+    the reference's own failure -- the missing hex_dict.p -- if none is there."""
+    import errno
+    import os
+    for name in DEFAULT_TABLE_FILES:
+        path = os.path.join(directory, name)
+        if os.path.exists(path):
+            return path
+    raise FileNotFoundError(errno.ENOENT, 'No such file or directory (nor normcons_dictionary.p / master_dictionary.p '
+                            'beside it; or call set_rate_table(...))', 'hex_dict.p')
+
+
 def write_hex_dict(path, dense, protocol=2):
     """``hex_dict.p`` as hex_dict_builder.py:143-147 writes it: {18-char '0'/'1' key -> ndarray(6)}, 2^18
     entries, for scripts that ``pickle.load`` it themselves (Mc_Lattice.py:64).  ``dense`` is the folded

@@ -190,3 +190,53 @@ def test_ensemble_is_the_same_at_any_rank_count(base512):
             assert np.array_equal(np.concatenate([l[key] for l in locs]), loc1[key]), key
         assert np.array_equal(acc[:, [0, 6, 7, 8, 9, 10, 11, 12]], acc1[:, [0, 6, 7, 8, 9, 10, 11, 12]])   # counts: exact
         np.testing.assert_allclose(acc, acc1, rtol=1e-13)                                                # sums: order of addition
+
+
+def test_dstar_against_the_published_files_master_table():
+    """north_star: "D*(x) within reference error bars".  The reference's published D*(x) files (data_run_4_data,
+    data_run_3_data; copies under tests/golden/) against this engine on the fold of master_dictionary.p, in the shape the
+    reference's own LiCoO2_kmc.out header shows (10 x 10, 100 + 100 cycles).  What holds and is asserted: D* rises by
+    decades with x on the master table, as in the files.  What does NOT hold, measured in profiles/r2_dstar_vs_reference.md
+    and pinned here so that it cannot change silently: every point lies ABOVE the files' mean + error, by 0.4 to 7.7
+    decades -- the files were not produced by the hex path at this revision (which this engine replays bit for bit,
+    test_golden_trajectory) on either committed table: parity with the published D*(x) is unpinned."""
+    import kmc_amd
+    from kmc_amd import ensemble
+    g = os.path.join(os.path.dirname(__file__), 'golden')
+    t = np.load(os.path.join(g, 'tables.npz'))
+    run4 = np.loadtxt(os.path.join(g, 'ref_data_run_4_data'), delimiter=',', skiprows=1)       # d_star, x, err, d_j, err_j
+    ref = {round(float(r[1]), 2): (float(r[0]), float(r[2])) for r in run4}
+    xs = [0.3, 0.5, 0.7, 0.9]
+    factory = lambda R, nx, ny, wm, dev: kmc_amd.KMCEngine(R, nx, ny, wm, dev)    # noqa: E731
+    fin, _ = ensemble.run_ensemble(factory, 10, 10, xs, 128, 100, 100, seed=ensemble.derive_seed(2025, 10),
+                                   table=('base', t['base512_master'], None))
+    d = {round(r['concentration'], 2): r['d_star'] for r in fin}
+    assert d[0.9] > 1e2 * d[0.3] and d[0.9] > d[0.7] > d[0.5]          # the files: 6.4e-12 / 4.9e-19
+    for x in xs:
+        mean, err = ref[x]
+        assert d[x] > mean + err, (x, d[x], mean, err)
+        assert 0.3 < np.log10(d[x] / mean) < 8.0, (x, d[x], mean)
+
+
+def test_rccl_allreduce_behind_the_c_abi(base512):
+    """kmc_allreduce_stats: the one collective as an RCCL call on the engine's stream.  A 1-GPU box can only form a
+    one-rank communicator (RCCL refuses two ranks on one device): unique id, communicator, the all-reduce (an
+    identity here), twice with growing buffers, teardown, and the argument checks.  The N-rank arithmetic is
+    covered by the gloo tests of tests/test_distributed_cpu.py; N ranks on N GPUs run it in bench.py --collective rccl."""
+    import kmc_amd
+    from kmc_amd import ensemble
+    uid = kmc_amd.KMCEngine.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    with kmc_amd.KMCEngine(4, 8) as eng:
+        comm = eng.comm_create(uid, 1, 0)
+        rs = np.random.RandomState(3)
+        for n in (13, 9 * 13, 5000):
+            acc = rs.rand(n)
+            assert np.array_equal(eng.allreduce_stats(comm, acc), acc)
+        acc2 = rs.rand(9, 13)
+        assert np.array_equal(ensemble.all_reduce_acc(acc2, rccl=(eng, comm)), acc2)
+        with pytest.raises(kmc_amd.engine.KMCError):
+            eng.allreduce_stats(None, acc)
+        with pytest.raises(kmc_amd.engine.KMCError):
+            eng.comm_create(uid, 2, 2)
+        eng.comm_destroy(comm)

@@ -197,3 +197,48 @@ def test_mc_lattice_class(tabs):
     assert np.array_equal(x.get_hex_probability([0, 0, 0]),
                           dense[O.site_key(rep.occ, 0, 0)] if rep.occ[0, 0] else np.zeros(6))
     x.close()
+
+
+def test_tables_load_from_the_working_directory(master_pickle, normcons_pickle, tabs, tmp_path, monkeypatch):
+    """Scripts of the reference never name a table: hex_dict.p is read from the working directory at import
+    (hex_LiCoO2_kmc.py:636, :644; Mc_Lattice.py:64).  Without set_rate_table the drop-ins do the same on first use --
+    hex_dict.p, else normcons_dictionary.p, else master_dictionary.p -- and fail like the reference when none is there.
+    ``kmc_amd.mc_lattice`` is the module name of the reference's stubs (mc_lattice.py)."""
+    import shutil
+    import kmc_amd.hex_LiCoO2_kmc as K
+    from kmc_amd import tables
+    from kmc_amd.mc_lattice import mc_lattice
+    from kmc_amd.Mc_Lattice import mc_lattice as same_class
+    assert mc_lattice is same_class
+    K.close()
+    K._table = None
+    mc_lattice.rate_table = None
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(FileNotFoundError, match='hex_dict.p'):
+        K.hex_table()
+    with pytest.raises(FileNotFoundError, match='hex_dict.p'):
+        mc_lattice([8, 8, 1]).fill_lattice(0.5)
+    # master_dictionary.p alone -> its fold (BASELINE config 1's table)
+    shutil.copy(master_pickle, tmp_path / 'master_dictionary.p')
+    dense_master = O.build_hex_table(tabs['base512_master'])
+    assert np.array_equal(K.hex_table(), dense_master)
+    x = mc_lattice([8, 8, 1])
+    x.fill_lattice(0.5)
+    occ = (x.lattice[:, :, 0] == '1').astype(np.uint8)
+    assert np.array_equal(x.probability_matrix[:, :, 0, :], O.rates_full(occ, dense_master))
+    x.close()
+    # normcons_dictionary.p beside it wins, hex_dict.p wins over both
+    K.close()
+    K._table = None
+    mc_lattice.rate_table = None
+    shutil.copy(normcons_pickle, tmp_path / 'normcons_dictionary.p')
+    dense = O.build_hex_table(tabs['base512_normcons'])
+    assert np.array_equal(K.hex_table(), dense)
+    K.close()
+    K._table = None
+    marked = dense.copy()
+    marked[5, 0] = 123.0
+    tables.write_hex_dict(str(tmp_path / 'hex_dict.p'), marked)
+    assert np.array_equal(K.hex_table(), marked)
+    K.close()
+    K._table = None

@@ -117,3 +117,15 @@ def test_hex_dict_writer_round_trip(tmp_path):
     assert kind == 'dense' and np.array_equal(arr, dense)
     d = tables.load_table_pickle(p)
     assert len(d) == 1 << 18 and np.array_equal(d['111100110011001111'], dense[249039])
+
+
+def test_default_table_lookup(tmp_path):
+    """hex_dict.p, else normcons_dictionary.p, else master_dictionary.p, else the reference's own failure."""
+    with pytest.raises(FileNotFoundError, match='hex_dict.p'):
+        tables.find_default_table(str(tmp_path))
+    for name in reversed(tables.DEFAULT_TABLE_FILES):
+        (tmp_path / name).write_bytes(b'')
+        assert os.path.basename(tables.find_default_table(str(tmp_path))) == name
+    import kmc_amd.mc_lattice as m1
+    import kmc_amd.Mc_Lattice as m2
+    assert m1.mc_lattice is m2.mc_lattice
