@@ -84,6 +84,9 @@ struct kmc_ctx {
     double margin_scale;
     uint32_t rid_base;     // kmc_set_replica_offset: global id of replica 0 (Philox counter word)
     double* coll_buf; size_t coll_cap;   // device staging of kmc_allreduce_stats (pooled)
+    void* pool; size_t pool_cap;         // device scratch of the per-call entry points (grown on demand, never shrunk):
+                                         // the drop-in kmc_step / kmc_evolve path calls them once per reference call
+    void* hpool; size_t hpool_cap;       // the same on the host
     char err[512];
 };
 
@@ -486,11 +489,28 @@ static __device__ __align__(256) long long kmc_noalloc_scratch[(size_t)KMC_NOALL
 // ======================================================================
 // host API
 // ======================================================================
-template <class T>
-static int dmalloc(kmc_ctx* c, T** p, size_t count)
+// Device / host scratch for one entry point at a time (a context is single-owner and its calls are stream-ordered;
+// every user synchronises the stream before it returns).
+static int dev_pool(kmc_ctx* c, size_t bytes, void** out)
 {
-    HIPCHK(c, hipMalloc((void**)p, count * sizeof(T) + 16));
-    return 0;
+    if (c->pool_cap < bytes) {
+        if (c->pool) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->pool)); }
+        c->pool = nullptr; c->pool_cap = 0;
+        const size_t cap = bytes < 65536 ? 65536 : bytes;
+        HIPCHK(c, hipMalloc(&c->pool, cap + 256));
+        c->pool_cap = cap;
+    }
+    *out = c->pool;
+    return KMC_OK;
+}
+static void* host_pool(kmc_ctx* c, size_t bytes)
+{
+    if (c->hpool_cap < bytes) {
+        free(c->hpool);
+        c->hpool = malloc(bytes < 65536 ? 65536 : bytes);
+        c->hpool_cap = c->hpool ? (bytes < 65536 ? 65536 : bytes) : 0;
+    }
+    return c->hpool;
 }
 
 static size_t host_hop_lds_bytes(int nx, int n)
@@ -620,8 +640,9 @@ int kmc_destroy(kmc_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     void* bufs[] = {c->occ, c->keys, c->tags, c->table, c->wsum, c->time_total, c->step_time, c->gamma, c->hist,
                     c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel, c->w_g, c->tcompact, c->tcompact2, c->hier, c->xscratch,
-                    c->coll_buf};
+                    c->coll_buf, c->pool};
     for (void* b : bufs) if (b) hipFree(b);
+    free(c->hpool);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     for (int k = 0; k < KMC_EV_RING; ++k) for (int g = 0; g < KMC_GROUPS; ++g) for (int q = 0; q < 2; ++q)
@@ -762,14 +783,13 @@ int kmc_set_base_table(kmc_ctx* c, const double* base512, double dumbbell)
     CTXCHK(c);
     if (!base512) return fail(c, KMC_EINVAL, "kmc_set_base_table: null table");
     double* dbase = nullptr;
-    HIPCHK(c, hipMalloc((void**)&dbase, 512 * 8));
+    if (int rc = dev_pool(c, 512 * 8, (void**)&dbase)) return rc;
     HIPCHK(c, hipMemcpyAsync(dbase, base512, 512 * 8, hipMemcpyHostToDevice, c->stream));
     time_begin(c);
     fold_table_kernel<<<KMC_TABLE_ROWS / 256, 256, 0, c->stream>>>(dbase, dumbbell, c->table, c->wsum);
     time_end(c);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(dbase));
     c->have_table = true;
     return build_compact(c);
 }
@@ -801,14 +821,13 @@ int kmc_generate_base_table(kmc_ctx* c, const double* eci47, double prefactor, d
     CTXCHK(c);
     if (!eci47 || !base512_out) return fail(c, KMC_EINVAL, "kmc_generate_base_table: null pointer");
     double* d = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d, (47 + 512 + 512) * 8 + 64));
+    if (int rc = dev_pool(c, (47 + 512 + 512) * 8 + 64, (void**)&d)) return rc;
     HIPCHK(c, hipMemcpyAsync(d, eci47, 47 * 8, hipMemcpyHostToDevice, c->stream));
     lce_rates_kernel<<<1, 512, 0, c->stream>>>(d, prefactor, kb_t, d + 48, d + 48 + 512);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(base512_out, d + 48, 512 * 8, hipMemcpyDeviceToHost, c->stream));
     if (energies_out) HIPCHK(c, hipMemcpyAsync(energies_out, d + 48 + 512, 512 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(d));
     return KMC_OK;
 }
 
@@ -912,16 +931,14 @@ int kmc_get_rates(kmc_ctx* c, double* P)
     // staged through a bounded device buffer so that 4096 x 64 x 64 (805 MB) needs no 805 MB of HBM
     const size_t chunk = Rn < ((size_t)1 << 22) ? Rn : ((size_t)1 << 22);
     double* d = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d, chunk * 48));
+    if (int rc = dev_pool(c, chunk * 48, (void**)&d)) return rc;
     for (size_t s0 = 0; s0 < Rn; s0 += chunk) {
         const size_t m = Rn - s0 < chunk ? Rn - s0 : chunk;
         materialize_rates_kernel<<<2048, 256, 0, c->stream>>>(c->keys + s0, m, c->table, d);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(P + s0 * 6, d, m * 48, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { hipFree(d); HIPCHK(c, e); }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(P + s0 * 6, d, m * 48, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    HIPCHK(c, hipFree(d));
     return KMC_OK;
 }
 
@@ -937,12 +954,11 @@ int kmc_refresh_window(kmc_ctx* c, const int32_t* se)
             return fail(c, KMC_EINVAL, "kmc_refresh_window: replica %d: start (%d,%d) / end (%d,%d) out of range", r, q[0], q[1], q[2], q[3]);
     }
     int* d = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d, (size_t)c->R * 16));
+    if (int rc = dev_pool(c, (size_t)c->R * 16, (void**)&d)) return rc;
     HIPCHK(c, hipMemcpyAsync(d, se, (size_t)c->R * 16, hipMemcpyHostToDevice, c->stream));
     refresh_window_kernel<<<c->R, 64, 0, c->stream>>>(c->occ, c->nx, c->ny, c->window_mode, d, c->keys);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(d));
     return KMC_OK;
 }
 
@@ -1304,13 +1320,11 @@ int kmc_gamma_exact(kmc_ctx* c, double* gamma)
     if (!gamma) return fail(c, KMC_EINVAL, "kmc_gamma_exact: null pointer");
     if (!c->have_keys || !c->have_table) return fail(c, KMC_ESTATE, "kmc_gamma_exact: needs a table and kmc_rates_full");
     double* d = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d, (size_t)c->R * 8));
+    if (int rc = dev_pool(c, (size_t)c->R * 8, (void**)&d)) return rc;
     gamma_exact_kernel<<<(c->R + 63) / 64, 64, 0, c->stream>>>(c->keys, c->R, c->n, c->table, d);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(gamma, d, (size_t)c->R * 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d);
-    HIPCHK(c, e);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(gamma, d, (size_t)c->R * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return KMC_OK;
 }
 
@@ -1320,15 +1334,15 @@ int kmc_diffusion(kmc_ctx* c, const double* conc, double a, double* dstar, doubl
     CTXCHK(c);
     if (!conc || !dstar || !dj) return fail(c, KMC_EINVAL, "kmc_diffusion: null pointer");
     long long* d = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d, (size_t)c->R * 32));
+    if (int rc0 = dev_pool(c, (size_t)c->R * 32, (void**)&d)) return rc0;
     msd_kernel<<<c->R, 256, 0, c->stream>>>(c->tags, c->nx, c->ny, d);
-    long long* h = (long long*)malloc((size_t)c->R * 32);
-    double* t = (double*)malloc((size_t)c->R * 8);
+    long long* h = (long long*)host_pool(c, (size_t)c->R * 40);
+    if (!h) return fail(c, KMC_EINVAL, "kmc_diffusion: out of host memory");
+    double* t = (double*)(h + (size_t)c->R * 4);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(h, d, (size_t)c->R * 32, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(t, c->time_total, (size_t)c->R * 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d);
     int rc = KMC_OK;
     if (e != hipSuccess) rc = fail(c, KMC_EHIP, "kmc_diffusion: %s", hipGetErrorString(e));
     for (int r = 0; rc == KMC_OK && r < c->R; ++r) {
@@ -1343,7 +1357,6 @@ int kmc_diffusion(kmc_ctx* c, const double* conc, double a, double* dstar, doubl
         dj[r] = pref * dj2 / n_atoms;
         if (msd_out) { msd_out[r * 4] = sq; msd_out[r * 4 + 1] = si; msd_out[r * 4 + 2] = sj; msd_out[r * 4 + 3] = cnt; }
     }
-    free(h); free(t);
     return rc;
 }
 
@@ -1485,13 +1498,11 @@ int kmc_get_distances(kmc_ctx* c, double a, double* matrix)
     if (!matrix) return fail(c, KMC_EINVAL, "kmc_get_distances: null pointer");
     const size_t Rn = (size_t)c->R * c->n;
     double* d = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d, Rn * 8));
+    if (int rc = dev_pool(c, Rn * 8, (void**)&d)) return rc;
     distance_kernel<<<1024, 256, 0, c->stream>>>(c->tags, c->nx, c->ny, Rn, a, d);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(matrix, d, Rn * 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d);
-    HIPCHK(c, e);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(matrix, d, Rn * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return KMC_OK;
 }
 
