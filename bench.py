@@ -196,11 +196,31 @@ def load_pmc(np, R_local, hops_per_step):
 
 
 # ---------------------------------------------------------------------------------------------- one measurement
-def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red_dev, keep_check):
+# The other BASELINE.json configs (parity-test cases, not the metric's workload) as `--config N` lines of the same
+# shape: n = lattice side, R = replicas (in total), conc = concentrations (cycled over the replicas, iteration-major as
+# kmc_amd.ensemble shards them), table, hops of one "step" per replica (None: one reference KMC step, int(n*n*x)).
+OTHER_CONFIGS = {
+    1: dict(n=30, R=1, conc=[0.5], table='master', step_hops=None,
+            what='config 1: single 30x30 hex lattice, x=0.5, master_dictionary.p table (its 512-key restriction folded)'),
+    2: dict(n=64, R=256, conc=[0.5], table='normcons', step_hops=None, what='config 2: 256 independent 64x64 replicas at x=0.5'),
+    3: dict(n=64, R=9 * 512, conc=[0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9], table='normcons', step_hops=None,
+            what='config 3: concentration sweep x=0.1..0.9, 9 points x 512 replicas of 64x64; a step = one reference KMC step = int(4096 x) hops per replica'),
+    4: dict(n=1024, R=1, conc=[0.5], table='normcons', step_hops=16384,
+            what='config 4: single 1024x1024 lattice, x=0.5; a step here = 16384 hops (a reference KMC step would be 524288)'),
+}
+
+
+def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red_dev, keep_check, cfg=None):
     """W warm-up + K timed steps on this rank's R replicas (global ids offset .. offset + R).  Returns a dict;
     `elapsed` is the max over ranks."""
+    n_side = cfg['n'] if cfg else N_SIDE
+    tabs = np.load(os.path.join(ROOT, 'tests', 'golden', 'tables.npz'))
+    base512 = tabs['base512_' + (cfg['table'] if cfg else 'normcons')]
+    if cfg:
+        conc = np.asarray(cfg['conc'], dtype=np.float64)[(offset + np.arange(R)) % len(cfg['conc'])]
+        hops_vec = (np.full(R, cfg['step_hops']) if cfg['step_hops'] else (n_side * n_side * 1 * conc)).astype(np.int64)
+        return measure_other(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red_dev, cfg, conc, hops_vec, base512)
     hops_per_step = int(N_SIDE * N_SIDE * 1 * CONC)
-    base512 = np.load(os.path.join(ROOT, 'tests', 'golden', 'tables.npz'))['base512_normcons']
     eng = kmc_amd.KMCEngine(R, N_SIDE, N_SIDE, window_mode='hex_ref', device=local_rank, replica_offset=offset)
     eng.set_base_table(base512, kmc_amd.tables.dumbbell_rate())
     fold_ms = eng.last_kernel_ms()
@@ -270,6 +290,52 @@ def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red
     return out
 
 
+def measure_other(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red_dev, cfg, conc, hops_vec, base512):
+    """measure() for the --config lines: per-replica concentrations and hop counts (kmc_run_counts)."""
+    n = cfg['n']
+    eng = kmc_amd.KMCEngine(R, n, n, window_mode='hex_ref', device=local_rank, replica_offset=offset)
+    eng.set_base_table(base512, kmc_amd.tables.dumbbell_rate())
+    eng.fill_random(conc, SEED)
+    eng.rates_full()
+    eng.run_counts(hops_vec, presim=True, seed=SEED)
+    eng.init_displacements()
+    for _ in range(args.warmup):
+        eng.run_counts(hops_vec, presim=False, seed=SEED)
+    eng.diffusion(conc)
+    ensemble.all_reduce_acc(np.zeros((1, len(ensemble.ACC_FIELDS))), red_dev)
+    eng.sync()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            if red_dev is not None:
+                torch.cuda.synchronize()
+        eng.sync()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run_counts(hops_vec, presim=False, seed=SEED)
+    ds, dj, _ = eng.diffusion(conc)
+    sc, st = eng.scalars(), eng.status()
+    point = ((offset + np.arange(R)) % len(cfg['conc'])).astype(np.int64)
+    acc = ensemble.accumulate(point, len(cfg['conc']), ds, dj, sc['time'], st['hops_done'].astype(np.float64), sc['hist'].astype(np.float64))
+    acc = ensemble.all_reduce_acc(acc, red_dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev if red_dev is not None else 'cpu')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    n_span = min(args.steps, 64)
+    span_ms, groups = eng.run_span_ms(n_span)
+    out = dict(elapsed=elapsed, k_ms=span_ms / n_span, groups=groups, R=R, n_exact=int(st['n_exact'].sum()),
+               stopped=int((st['status'] != 0).sum()), stats=ensemble.finalize(acc, cfg['conc']), step_hops_rank=int(hops_vec.sum()),
+               lds_bytes=eng.lds_bytes, lds_path=eng.uses_lds_path)
+    eng.close()
+    return out
+
+
 def shard(total, rank, world):
     lo, hi = total * rank // world, total * (rank + 1) // world
     return hi - lo, lo
@@ -285,6 +351,8 @@ def main():
     ap.add_argument('--collective', choices=('torch', 'rccl'), default='torch',
                     help='transport of the one all-reduce: torch.distributed (backend nccl = RCCL), or kmc_allreduce_stats '
                          '(an RCCL communicator of the engine\'s own, behind the C ABI)')
+    ap.add_argument('--config', type=int, default=5, choices=(1, 2, 3, 4, 5),
+                    help='BASELINE.json config to run: 5 (default) is the metric\'s workload; 1-4 are its parity-test cases')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -321,6 +389,35 @@ def main():
         if scaling == 'weak':
             return args.replicas, rank * args.replicas
         return shard(args.replicas, rank, world)
+
+    if args.config != 5:
+        cfg = OTHER_CONFIGS[args.config]
+        # every rank runs the whole configuration's share: replicas sharded strong (a fixed ensemble), a single
+        # lattice does not shard (replicas only) -- then every rank runs its own
+        Rc, offc = shard(cfg['R'], rank, world) if cfg['R'] >= world else (cfg['R'], rank * cfg['R'])
+        mo = measure(kmc_amd, ensemble, np, args, Rc, offc, local_rank, dist, torch, red_dev, 0, cfg)
+        hops_all = mo['step_hops_rank']
+        if dist is not None:
+            tt = torch.tensor([float(hops_all)], dtype=torch.float64, device=red_dev if red_dev is not None else 'cpu')
+            dist.all_reduce(tt)
+            hops_all = float(tt.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            kern = ('hop_q64_kernel' if cfg['n'] == 64 else 'hop_lds_kernel') if mo['lds_path'] else 'hop_big_kernel'
+            print(json.dumps({
+                'metric': 'KMC hops/sec, BASELINE config %d (a parity-test case, not the headline workload)' % args.config,
+                'value': hops_all * args.steps / mo['elapsed'], 'unit': 'hops/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': mo['elapsed'] / args.steps * 1e3, 'higher_is_better': True,
+                'scaling': 'strong' if cfg['R'] >= world else 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+                'config': {'workload': cfg['what'], 'replicas_total': cfg['R'] if cfg['R'] >= world else cfg['R'] * world,
+                           'lattice': [cfg['n'], cfg['n']], 'concentrations': cfg['conc'], 'hops_per_step_all_replicas': hops_all, 'seed': SEED},
+                'roofline': {'bound': 'latency (one wave\'s dependent chain)' if cfg['R'] < 3072 else 'valu_busy', 'achieved': None, 'peak': None, 'unit': None,
+                             'frac': None, 'traffic': None, 'kernel': kern, 'kernel_ms': mo['k_ms'], 'launches_per_step': mo['groups'],
+                             'note': 'no PMC pass is kept for this configuration; the headline line (--config 5) carries the roofline'},
+                'kernel_hops_per_s': mo['step_hops_rank'] / (mo['k_ms'] * 1e-3), 'exact_path_hops': mo['n_exact'],
+                'stopped_replicas': mo['stopped'], 'd_star_by_concentration': [[r['concentration'], r['d_star'], r['error_star']] for r in mo['stats']]}))
+        return
 
     R, offset = replicas_of(args.scaling)
     m = measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red_dev,

@@ -507,15 +507,16 @@ void hop_q64_kernel(HopParams p)
             if (!presim) {
                 const unsigned long long m = ballot64((tg_sv & 0xFFFF) == s_src);
                 const int wrap = ((ie >> 6) << 8) + ((je >> 6) << 16);      // floor(ie / 64) = -1, 0, +1
-                if (m) {
-                    asm volatile("");              // the atom came with an earlier hop of this chunk
-                    const int lm = __ffsll((long long)m) - 1;
-                    const int osv = __builtin_amdgcn_readlane(tg_sv, lm), oow = __builtin_amdgcn_readlane(tg_ow, lm);
-                    writelane2(tg_sv, tg_ow, (osv & (int)0xFFFF0000) | s_dst, oow + wrap, lm);
-                } else {
-                    asm volatile("");              // its tag is still in memory, at s_src
-                    writelane2(tg_sv, tg_ow, s_dst | (s_src << 16), (64 << 8) + (64 << 16) + wrap, hl);
-                }
+                // One straight line for both cases (a taken branch costs a wave ~27 cycles, a not-taken one ~11:
+                // scripts/probes/valu_rate_probe.hip): the atom either came with an earlier hop of this chunk (its
+                // lane lm keeps the site it entered the chunk from and gathers the wrap) or its tag is still in
+                // memory at s_src (it takes lane hl, free by construction).  Scalar selects, two lane reads, two writes.
+                const bool seen = m != 0ull;
+                const int lm = seen ? (int)__builtin_ctzll(m) : hl;
+                const int osv = __builtin_amdgcn_readlane(tg_sv, lm), oow = __builtin_amdgcn_readlane(tg_ow, lm);
+                const int nsv = (seen ? (osv & (int)0xFFFF0000) : (s_src << 16)) | s_dst;
+                const int now_ = (seen ? oow : (64 << 8) + (64 << 16)) + wrap;
+                writelane2(tg_sv, tg_ow, nsv, now_, lm);
             }
             const double sumA = group8_sum(wA0 + wA1);
             KMC_STAMP(4);
@@ -527,9 +528,6 @@ void hop_q64_kernel(HopParams p)
                 const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(sumA));
                 const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(sumA));
                 const double nA = __hiloint2double(hi, lo);
-                // qa is uniform: a branch and one select instead of four selects
-                // (four separate uniform tests rather than a switch: each updates its register in place, a
-                // switch makes the compiler copy the others around)
                 if (qa == 0) { asm volatile(""); Q0 = take ? nA : Q0; }
                 if (qa == 1) { asm volatile(""); Q1 = take ? nA : Q1; }
                 if (qa == 2) { asm volatile(""); Q2 = take ? nA : Q2; }

@@ -13,10 +13,12 @@ if sys.argv[1] == '--build':
                               stderr=subprocess.DEVNULL)
         print(out)
 else:
-    for rep in range(2):
-        for name in sys.argv[2:]:
-            env = dict(os.environ, KMC_AMD_LIB=os.path.join(ROOT, 'kmc_amd', 'libkmc_hip_v_%s.so' % name))
-            o = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'time_calls.py')], env=env,
-                               capture_output=True, text=True, timeout=120).stdout.strip().split('\n')
-            ks = [float(l.split('kernel')[1].split()[0]) for l in o if 'kernel' in l]
-            print('%-12s presim %.3f  sim %.3f ms (min of 3)' % (name, min(ks[0::2]), min(ks[1::2])), flush=True)
+    # KMC_VAR_R: replica counts to time (default 4096: four waves per SIMD; 256 = one wave per CU, alone on its SIMD)
+    for R in [int(x) for x in os.environ.get('KMC_VAR_R', '4096').split(',')]:
+        for rep in range(2):
+            for name in sys.argv[2:]:
+                env = dict(os.environ, KMC_AMD_LIB=os.path.join(ROOT, 'kmc_amd', 'libkmc_hip_v_%s.so' % name))
+                o = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'time_calls.py'), str(R)], env=env,
+                                   capture_output=True, text=True, timeout=120).stdout.strip().split('\n')
+                ks = [float(l.split('kernel')[1].split()[0]) for l in o if 'kernel' in l]
+                print('R %5d %-12s presim %.3f  sim %.3f ms (min of 3)' % (R, name, min(ks[0::2]), min(ks[1::2])), flush=True)
