@@ -291,6 +291,93 @@ __global__ __launch_bounds__(256) void rates_full_kernel(const uint8_t* __restri
     }
 }
 
+
+// Rows R1, R2 for lattices up to 64 x 64 (every LDS-path lattice; the headline's 4096 x 64 x 64 = 16.8 M sites):
+// one wave per replica, lane j = lattice column j.  The kernel is HBM-bound by design -- 1 B read + 4 B written per
+// site -- so the work per byte is kept low: each lane packs its column into a 64-bit bitmap straight from coalesced
+// byte loads (a wave-instruction reads one 64-byte lattice row), fetches the four neighbouring columns' bitmaps once
+// (ds_bpermute: no LDS memory, no barrier) and then every key is five 5-row windows of those registers: a funnel
+// shift and a bit-field extract per column (the key's chars run column by column, kmc_device.h key_from_cols).
+// Stores are one dword per lane = 256 contiguous bytes per wave-instruction.  NX = 64: the row loop is unrolled and
+// every shift is an immediate; NX = 0: any 5 <= nx, ny <= 64 (run-time rotates).
+// Measured (scripts/time_rates_full.py, profiles/r2_rates_full.txt): 4096 x 64 x 64 in 18.0 us = 4.7 TB/s, 16384
+// replicas at 5.7 TB/s (0.58 / 0.71 of the 8 TB/s peak; the stream is 80 % writes); two waves per replica (32 rows
+// each) were 7 % slower.  rates_full_kernel below (byte tiles in LDS, 18 LDS byte reads per key; any lattice size)
+// needs 49 us for the same, 0.21 of the peak.
+template <int NX>
+__global__ __launch_bounds__(64) void rates_cols_kernel(const uint8_t* __restrict__ occ, int R, int nx_rt, int ny,
+                                                         uint32_t* __restrict__ keys)
+{
+    const int nx = NX ? NX : nx_rt;
+    // lattices of up to 32 (16) columns: two (four) replicas per wave, each in its own group of lanes
+    const int gw = NX ? 64 : (ny <= 16 ? 16 : (ny <= 32 ? 32 : 64));
+    const int lane_w = threadIdx.x, lane = lane_w & (gw - 1), lane0 = lane_w - lane;
+    const int r = (int)blockIdx.x * (64 / gw) + lane_w / gw, n = nx * ny;
+    const bool live = lane < ny && r < R;
+    const uint8_t* o = occ + (live ? (size_t)r * n + lane : 0);
+    uint64_t c0 = 0;
+    if (NX) {
+#pragma unroll
+        for (int i0 = 0; i0 < NX; i0 += 16) {
+            uint32_t b[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) b[k] = o[(i0 + k) * ny];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) c0 |= (uint64_t)(b[k] & 1u) << (i0 + k);
+        }
+    } else {
+        for (int i = 0; i < nx; ++i) c0 |= (uint64_t)(o[i * ny] & 1u) << i;
+    }
+    if (!live) c0 = 0;
+    // neighbouring columns j +- 1, j +- 2 (periodic in ny)
+    auto from = [&](int dj) -> uint64_t {
+        int src = lane + dj;
+        src = lane0 + (src < 0 ? src + ny : (src >= ny ? src - ny : src));
+        const int lo = __builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)c0);
+        const int hi = __builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)(c0 >> 32));
+        return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+    };
+    const uint64_t p2 = from(2), p1 = from(1), m1 = from(-1), m2 = from(-2);
+    uint32_t* out = keys + (live ? (size_t)r * n + lane : 0);
+    // window of column c at row i: bits (i-2 .. i+2) mod nx.  Rotate every column left by 2 once, so that bit i of the
+    // rotated bitmap is row i - 2; rows whose window runs over the top take it from a second copy rotated by 32 more.
+    auto rotl = [&](uint64_t c, int k) -> uint64_t {        // rotate left by k within nx bits, 0 < k < nx
+        const uint64_t m = nx == 64 ? ~0ull : ((1ull << nx) - 1ull);
+        return ((c << k) | (c >> (nx - k))) & m;
+    };
+    if (NX == 64) {
+        const uint64_t a[5] = {rotl(p2, 2), rotl(p1, 2), rotl(c0, 2), rotl(m1, 2), rotl(m2, 2)};
+        uint64_t b[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) b[k] = (a[k] >> 32) | (a[k] << 32);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            uint32_t w[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const uint64_t v = i < 32 ? a[k] : b[k];
+                w[k] = __builtin_amdgcn_alignbit((uint32_t)(v >> 32), (uint32_t)v, (uint32_t)(i & 31));
+            }
+            uint32_t key = ((w[0] & 7u) << 15) | ((w[1] & 15u) << 11) | (((w[2] >> 3) & 3u) << 9) | ((w[2] & 3u) << 7) |
+                           (((w[3] >> 1) & 15u) << 3) | ((w[4] >> 2) & 7u);
+            key = ((w[2] >> 2) & 1u) ? key : KMC_VACANT;
+            if (live) out[i * 64] = key;
+        }
+    } else {
+        for (int i = 0; i < nx; ++i) {
+            int st = i - 2;
+            if (st < 0) st += nx;
+            const int sl = (nx - st) & 63;
+            auto win = [&](uint64_t c) -> uint32_t { return (uint32_t)((c >> st) | (c << sl)) & 31u; };
+            const uint32_t w2 = win(p2), w1 = win(p1), w0 = win(c0), v1 = win(m1), v2 = win(m2);
+            uint32_t key = ((w2 & 7u) << 15) | ((w1 & 15u) << 11) | (((w0 >> 3) & 3u) << 9) | ((w0 & 3u) << 7) |
+                           (((v1 >> 1) & 15u) << 3) | ((v2 >> 2) & 7u);
+            key = ((w0 >> 2) & 1u) ? key : KMC_VACANT;
+            if (live) out[i * ny] = key;
+        }
+    }
+}
+
 // P[s] = T[key[s]] (or zeros): the rate matrix of the stale-key state
 __global__ __launch_bounds__(256) void materialize_rates_kernel(const uint32_t* __restrict__ keys, size_t total,
                                                                  const double* __restrict__ table, double* __restrict__ P)
@@ -878,6 +965,16 @@ int kmc_fill_random(kmc_ctx* c, const double* conc, uint64_t seed)
 // ---------------------------------------------------------------- rates
 static int launch_rates_full(kmc_ctx* c, double* P)
 {
+    if (!P && c->nx >= 5 && c->ny >= 5 && c->nx <= 64 && c->ny <= 64) {
+        if (c->nx == 64 && c->ny == 64)
+            rates_cols_kernel<64><<<c->R, 64, 0, c->stream>>>(c->occ, c->R, c->nx, c->ny, c->keys);
+        else {
+            const int per_wave = c->ny <= 16 ? 4 : (c->ny <= 32 ? 2 : 1);
+            rates_cols_kernel<0><<<(c->R + per_wave - 1) / per_wave, 64, 0, c->stream>>>(c->occ, c->R, c->nx, c->ny, c->keys);
+        }
+        HIPCHK(c, hipGetLastError());
+        return KMC_OK;
+    }
     const int ti = (c->nx + RF_TI - 1) / RF_TI, tj = (c->ny + RF_TJ - 1) / RF_TJ;
     const long long blocks = (long long)c->R * ti * tj;
     if (blocks > 0x7fffffffLL) return fail(c, KMC_EINVAL, "rates_full: grid too large");
