@@ -96,6 +96,19 @@ struct BigCtrl {                 // wave 0 -> the helper waves
     uint32_t kscr[6 * 8];        // new keys of the window, [window row][window column]
 };
 
+// Parameters used at chunk boundaries and at the ends of the kernel only are re-read from the kernel-argument
+// segment there (scalar loads through the constant cache) instead of occupying scalar registers for the whole hop
+// loop, which at ~100 live scalars spills them through vector lanes (163 spill slots, ~160 v_readlane / v_writelane
+// per hop before this); see q64_cold_params (kmc_hop_q64.h).
+typedef const __attribute__((address_space(4))) HopBigParams* big_params_ptr;
+__device__ __forceinline__ big_params_ptr big_cold_params()
+{
+    big_params_ptr kp = (big_params_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+}
+#define BP (big_cold_params())
+
 template <bool COMPACT>
 __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p)
 {
@@ -110,7 +123,9 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     double* rowsum = reinterpret_cast<double*>(smem + bm_bytes + 256 + ((sizeof(ExactParShared) + 15) & ~(size_t)15));   // [nr1 * 8]
     double* R1 = rowsum + (size_t)g.nr1 * 8;                                                                             // [nr2 * 8]
 
-    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // (readfirstlane: the wave index is wave-uniform, which the compiler cannot see in tid >> 6 -- with it the hop loop's
+    // control flow is scalar branches and its uniform values stay scalar)
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint8_t* occ_g = p.occ + (size_t)r * n;
     uint32_t* keys_g = p.keys + (size_t)r * n;
     int4* tags_g = p.tags + (size_t)r * n;
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             while ((sq = *vseq) == seen) __builtin_amdgcn_s_sleep(16);
             seen = sq;
             if (*vstop) break;
-            exact_select_par(keys_g, p.table, n, *(volatile double*)&ctl->rho, xp);
+            exact_select_par(keys_g, BP->table, n, *(volatile double*)&ctl->rho, xp);
         }
     }
     double rho_v = 0.5, u_v = 1.0, gam_v = 1.0, pn_v = 1.0;
@@ -263,14 +278,15 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             // ---- uniforms for the next 64 hops, one hop per lane ---------------------------
             const int cnt = (int)((my_hops - h) < 64 ? (my_hops - h) : 64);
             rho_v = 0.5; u_v = 1.0; gam_v = 1.0; pn_v = 1.0; idx_v = -1;
+            const big_params_ptr bp = BP;               // taken here, in wave-uniform control flow
             if (lane < cnt) {
-                if (p.draws) {
-                    const double2 dv = reinterpret_cast<const double2*>(p.draws)[(size_t)r * p.n_hops + h + lane];
+                if (bp->draws) {
+                    const double2 dv = reinterpret_cast<const double2*>(bp->draws)[(size_t)r * bp->n_hops + h + lane];
                     rho_v = dv.x; u_v = dv.y;
                 } else {
                     const unsigned long long hh = (unsigned long long)(hop0 + h + lane);
-                    u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r + p.rid_base; c.w = KMC_STREAM_HOP;
-                    const u32x4 o = philox4x32_10(c, p.seed_lo, p.seed_hi);
+                    u32x4 c; c.x = (uint32_t)hh; c.y = (uint32_t)(hh >> 32); c.z = (uint32_t)r + bp->rid_base; c.w = KMC_STREAM_HOP;
+                    const u32x4 o = philox4x32_10(c, bp->seed_lo, bp->seed_hi);
                     rho_v = u53(o.x, o.y); u_v = u53_open0(o.z, o.w);
                 }
             }
@@ -545,7 +561,8 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
                 const double dt = lane < done ? (-1.0 / gam_v) * log(u_v) : 0.0;      // :530
                 time_acc += wave_sum(dt);
             }
-            if (p.sel && lane < done) p.sel[(size_t)r * p.n_hops + h0 + lane] = idx_v & 0x3FFFFFFF;
+            const big_params_ptr bp = BP;
+            if (bp->sel && lane < done) bp->sel[(size_t)r * bp->n_hops + h0 + lane] = idx_v & 0x3FFFFFFF;
             const bool has = lane < done && (idx_v & 0x3FFFFFFF) != 0;               // :495
             const double pd_v = (idx_v & (1 << 30)) ? 1.0 : gam_v;
             const double bar = has ? -log((pn_v / pd_v) / 1e13) * 0.025 : 0.0;      // :496-498
@@ -571,7 +588,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         __threadfence_block();
         if (lane == 0) { *(volatile double*)&ctl->rho = rho; *(volatile int*)&ctl->seq = ++seq_sent; }
         else ++seq_sent;
-        exact_select_par(keys_g, p.table, n, rho, xp);
+        exact_select_par(keys_g, BP->table, n, rho, xp);
         ++n_exact;
         if (!(xp->gamma > 0.0)) { status = 2; break; }
         if (xp->idx >= 6LL * n) { status = 1; break; }
@@ -586,6 +603,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         occ_g[s] = (uint8_t)((bm[bm_word(row, col)] >> ((row + 2) & 31)) & 1u);
     }
     if (wv == 0) {
+        const big_params_ptr bp = BP;
         if (status != 0 && hops < my_hops) {
             // a replica that stopped: records of the unfinished chunk, then the trace of what never ran
             const int done = (int)(hops & 63);
@@ -596,7 +614,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
                     const double dt = lane < done ? (-1.0 / gam_v) * log(u_v) : 0.0;
                     time_acc += wave_sum(dt);
                 }
-                if (p.sel && lane < done) p.sel[(size_t)r * p.n_hops + h0 + lane] = idx_v & 0x3FFFFFFF;
+                if (bp->sel && lane < done) bp->sel[(size_t)r * bp->n_hops + h0 + lane] = idx_v & 0x3FFFFFFF;
                 const bool has = lane < done && (idx_v & 0x3FFFFFFF) != 0;
                 const double pd_v = (idx_v & (1 << 30)) ? 1.0 : gam_v;
                 const double bar = has ? -log((pn_v / pd_v) / 1e13) * 0.025 : 0.0;
@@ -614,24 +632,24 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
                 }
             }
         }
-        if (p.sel)
-            for (long long hh = hops + lane; hh < p.n_hops; hh += 64) p.sel[(size_t)r * p.n_hops + hh] = -1;
-        if (lane < 6) p.hist[r * 6 + lane] += hist_v;
+        if (bp->sel)
+            for (long long hh = hops + lane; hh < bp->n_hops; hh += 64) bp->sel[(size_t)r * bp->n_hops + hh] = -1;
+        if (lane < 6) bp->hist[r * 6 + lane] += hist_v;
         if (lane == 0) {
-            p.time_total[r] += time_acc;
-            p.step_time[r] = time_acc;
-            p.gamma[r] = gamma;
-            p.hops_done[r] = hop0 + hops;
-            p.n_exact[r] += n_exact;
-            p.status[r] |= status;
-            p.barrier[r * 5 + 0] = b_last;
-            p.barrier[r * 5 + 1] += b_sum;
-            p.barrier[r * 5 + 2] = fmin(p.barrier[r * 5 + 2], b_min);
-            p.barrier[r * 5 + 3] = fmax(p.barrier[r * 5 + 3], b_max);
-            p.barrier[r * 5 + 4] += b_cnt;
+            bp->time_total[r] += time_acc;
+            bp->step_time[r] = time_acc;
+            bp->gamma[r] = gamma;
+            bp->hops_done[r] = hop0 + hops;
+            bp->n_exact[r] += n_exact;
+            bp->status[r] |= status;
+            bp->barrier[r * 5 + 0] = b_last;
+            bp->barrier[r * 5 + 1] += b_sum;
+            bp->barrier[r * 5 + 2] = fmin(bp->barrier[r * 5 + 2], b_min);
+            bp->barrier[r * 5 + 3] = fmax(bp->barrier[r * 5 + 3], b_max);
+            bp->barrier[r * 5 + 4] += b_cnt;
 #ifdef KMC_STAMPS
-            if (p.stamps)
-                for (int k = 0; k < 8; ++k) p.stamps[r * 8 + k] = (long long)st_acc[k];
+            if (bp->stamps)
+                for (int k = 0; k < 8; ++k) bp->stamps[r * 8 + k] = (long long)st_acc[k];
 #endif
         }
     }
