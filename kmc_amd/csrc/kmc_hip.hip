@@ -5,6 +5,7 @@
 // Entry points are declared in include/kmc_hip.h with the reference lines each
 // one replaces.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <dlfcn.h>
 #include <rccl/rccl.h>          // types and enums only: the library itself is opened at run time (rccl_api)
 #include <math.h>
@@ -1255,13 +1256,33 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     const bool gen_w4 = gen_lds * 16 <= 160 * 1024 && c->R > 256 * 12;
     const int per_cu = c->lds64 ? (c->q64 ? 16 : 8) : (gen_w4 ? 16 : (gen_lds * 12 <= 160 * 1024 ? 12 : (int)((160 * 1024) / gen_lds)));
     const bool split = c->R >= 2 * 8 && (c->split == 2 || (c->split == 0 && c->R > 192 * per_cu));
+    const int r_half = ((c->R / 2 + 7) / 8) * 8;             // multiples of 8: blocks go round the 8 XCDs
+    if (counts && c->R > 1) {
+        // Per-replica hop counts (a sweep: int(n x) hops per step, a factor 9 between x = 0.1 and 0.9): workgroups are
+        // dispatched in block order and a launch lasts as long as its last replica, so the longest runs go first and
+        // the short ones fill the tail.  With two launch groups each group orders ITS OWN replicas: a replica must stay
+        // on its group's stream, because consecutive runs of different groups are not ordered against each other.
+        int* h = (int*)host_pool(c, (size_t)c->R * sizeof(int));
+        if (!h) return fail(c, KMC_EINVAL, "kmc_run_counts: out of host memory");
+        for (int r = 0; r < c->R; ++r) h[r] = r;
+        auto longer = [&](int a, int b) { return counts[a] > counts[b]; };
+        if (split) {
+            std::stable_sort(h, h + r_half, longer);
+            std::stable_sort(h + r_half, h + c->R, longer);
+        } else {
+            std::stable_sort(h, h + c->R, longer);
+        }
+        int* dorder = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(c->scratch_d) + (size_t)c->R * 8);
+        HIPCHK(c, hipMemcpyAsync(dorder, h, (size_t)c->R * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        p.order = dorder;
+    }
     if (split) {
         if (c->need_fork) {
             HIPCHK(c, hipEventRecord(c->fork_ev, c->stream));
             for (int g = 0; g < KMC_GROUPS; ++g) HIPCHK(c, hipStreamWaitEvent(c->gstream[g], c->fork_ev, 0));
             c->need_fork = false;
         }
-        const int r_half = ((c->R / 2 + 7) / 8) * 8;         // multiples of 8: blocks go round the 8 XCDs
         c->run_groups[slot] = KMC_GROUPS;
         for (int g = 0; g < KMC_GROUPS; ++g) {
             p.r_base = g == 0 ? 0 : r_half;

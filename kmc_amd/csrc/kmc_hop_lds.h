@@ -67,6 +67,8 @@ struct HopParams {
     void* xscratch;              // [R][Q64_XSCRATCH] exact-path scratch of hop_q64_kernel
     const double* tcompact2;     // [3][2^15][2] pair tables (hop_q64_kernel<true>) or null
     int r_base;                  // replica of block 0 (a run may be launched as several groups)
+    const int* order;            // [R] or null: block b runs replica order[b] (kmc_run_counts: longest runs first, so that
+                                 // the replicas with few hops fill the tail of the launch instead of the other way round)
     uint32_t rid_base;           // global id of the context's replica 0 (kmc_set_replica_offset): the Philox counter
                                  // word is rid_base + r, so an ensemble sharded over contexts / GPUs draws what one context would
 };
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
 static __device__ __forceinline__ void hop_lds_body(const HopParams& p, unsigned char* smem)
 {
-    const int r = blockIdx.x + p.r_base, lane = threadIdx.x;
+    const int r = p.order ? p.order[blockIdx.x + p.r_base] : (int)blockIdx.x + p.r_base, lane = threadIdx.x;
     const int nx = p.nx, ny = p.ny, n = p.n;
     size_t off_blk, off_col, off_frames;
     hop_lds_layout(nx, n, &off_blk, &off_col, &off_frames);

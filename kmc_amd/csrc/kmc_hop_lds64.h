@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K64_WAVES_PE
 void hop_lds64_kernel(HopParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int r = blockIdx.x + p.r_base, lane = threadIdx.x;
+    const int r = p.order ? p.order[blockIdx.x + p.r_base] : (int)blockIdx.x + p.r_base, lane = threadIdx.x;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     uint16_t* klo = reinterpret_cast<uint16_t*>(smem + K64_KLO);
     uint8_t* khi = smem + K64_KHI;

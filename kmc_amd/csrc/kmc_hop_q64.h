@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Q64_WAVES_PE
 void hop_q64_kernel(HopParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int r = blockIdx.x + p.r_base, lane = threadIdx.x;
+    const int r = p.order ? p.order[blockIdx.x + p.r_base] : (int)blockIdx.x + p.r_base, lane = threadIdx.x;
 #if defined(KMC_STAMPS) && KMC_STAMPS == 2
     const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
