@@ -359,6 +359,15 @@ def main():
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    # Only the JSON line may reach stdout: libraries under us write there too (gloo's "[Gloo] Rank 0 is connected ..."),
+    # so file descriptor 1 is pointed at stderr for the run and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + '\n').encode())
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -405,7 +414,7 @@ def main():
             dist.destroy_process_group()
         if rank == 0:
             kern = ('hop_q64_kernel' if cfg['n'] == 64 else 'hop_lds_kernel') if mo['lds_path'] else 'hop_big_kernel'
-            print(json.dumps({
+            emit({
                 'metric': 'KMC hops/sec, BASELINE config %d (a parity-test case, not the headline workload)' % args.config,
                 'value': hops_all * args.steps / mo['elapsed'], 'unit': 'hops/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': mo['elapsed'] / args.steps * 1e3, 'higher_is_better': True,
@@ -416,7 +425,7 @@ def main():
                              'frac': None, 'traffic': None, 'kernel': kern, 'kernel_ms': mo['k_ms'], 'launches_per_step': mo['groups'],
                              'note': 'no PMC pass is kept for this configuration; the headline line (--config 5) carries the roofline'},
                 'kernel_hops_per_s': mo['step_hops_rank'] / (mo['k_ms'] * 1e-3), 'exact_path_hops': mo['n_exact'],
-                'stopped_replicas': mo['stopped'], 'd_star_by_concentration': [[r['concentration'], r['d_star'], r['error_star']] for r in mo['stats']]}))
+                'stopped_replicas': mo['stopped'], 'd_star_by_concentration': [[r['concentration'], r['d_star'], r['error_star']] for r in mo['stats']]})
         return
 
     R, offset = replicas_of(args.scaling)
@@ -492,8 +501,7 @@ def main():
         out['other_scaling'] = other
     if not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(np, m['base512'], m['check'], host_threads())
-    print(json.dumps(out))
-    sys.stdout.flush()
+    emit(out)
 
 
 if __name__ == '__main__':

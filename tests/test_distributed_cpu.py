@@ -150,3 +150,21 @@ def test_shard_replicas_is_a_partition_at_any_world_size():
     # seeds of neighbouring lattice sizes are unrelated (seed + dimension would collide with seed + 1, dimension - 1)
     assert ensemble.derive_seed(5, 11) != ensemble.derive_seed(6, 10)
     assert len({ensemble.derive_seed(s, d) for s in range(20) for d in range(20)}) == 400
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    """`python bench.py --gpus 2` with no WORLD_SIZE spawns two rank processes before touching a GPU and exits
+    non-zero when one fails.  Here (no GPU) every rank fails at kmc_create -- the engine has no CPU backend -- so the
+    launcher must say which rank and return its code, with nothing on stdout; on a GPU box the same command prints
+    the one JSON line with n_gpus = 2."""
+    import json
+    env = dict(os.environ, KMC_BENCH_BACKEND='gloo', OMP_NUM_THREADS='1')
+    env.pop('WORLD_SIZE', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                          '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=300)
+    if out.returncode == 0:                       # a GPU is present
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1 and json.loads(lines[0])['n_gpus'] == 2
+    else:
+        assert out.stdout.strip() == ''
+        assert 'bench.py: rank' in out.stderr and 'no CPU backend' in out.stderr
