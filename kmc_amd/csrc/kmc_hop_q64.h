@@ -333,6 +333,18 @@ void hop_q64_kernel(HopParams p)
             // ---- quarter: every lane decides for its own row, lane i's answer counts ----
             const double p2 = Q0 + Q1;
             const double c1 = rowex + Q0, c2 = rowex + p2, c3 = rowex + (p2 + Q2);
+#ifndef Q64_QPICK_SCALAR
+            // per-lane answer of every row (selects), lane i's read with three lane reads: no ballots handed to the
+            // scalar unit, no branch tree.  A wave's hop is a chain of vector -> scalar -> vector hand-offs and their
+            // latencies, not its instruction slots, set its length: this and the entry pick below, both +9 vector
+            // instructions, are -1.4 % at 4096 replicas and -4.4 % at 256 (scripts/variants.py; the scalar versions are
+            // kept under Q64_QPICK_SCALAR / Q64_EPICK_SCALAR)
+            const bool l1 = c1 < t, l2 = c2 < t, l3 = c3 < t;
+            const double qb_l = l3 ? c3 : (l2 ? c2 : (l1 ? c1 : rowex));
+            const int q_l = (int)l1 + (int)l2 + (int)l3;
+            const int q = __builtin_amdgcn_readlane(q_l, i);
+            const double qbase = readlane_f64(qb_l, i);
+#else
             const unsigned long long b1 = ballot64(c1 < t), b2 = ballot64(c2 < t), b3 = ballot64(c3 < t);
             const int q = (int)((b1 >> i) & 1ull) + (int)((b2 >> i) & 1ull) + (int)((b3 >> i) & 1ull);
             double qbase;                  // q is uniform: a branch and one read-lane instead of six selects
@@ -342,6 +354,7 @@ void hop_q64_kernel(HopParams p)
             case 2: asm volatile(""); qbase = readlane_f64(c2, i); break;
             default: asm volatile(""); qbase = readlane_f64(c3, i); break;
             }
+#endif
             KMC_STAMP(1);
             // ---- entry: 16 sites x 6 directions, two entries per lane on 48 lanes ----------
             const uint32_t ek = (uint32_t)klo[i * 64 + q * 16 + ent_site] |
@@ -359,6 +372,18 @@ void hop_q64_kernel(HopParams p)
             const double ap = qbase + esc;
             const double ape = qbase + dpp_f64<0x138, 0xF>(esc);
             const double a0 = ape + rr.x;
+#ifndef Q64_EPICK_SCALAR
+            // every lane settles its own candidate (first or second entry), one ballot picks the lane
+            const bool first = a0 >= t;
+            const double lo_l = first ? ape : a0, hi_l = first ? a0 : ap, rate_l = first ? rr.x : rr.y;
+            const bool ok_l = (hi_l - t >= M) & (t - lo_l >= M) & (rate_l > 0.0);
+            const unsigned long long me = ballot64(ap >= t) & 0xFFFFFFFFFFFFull;       // a0 >= t implies ap >= t
+            const int el = (__ffsll((long long)me) - 1) & 63;
+            const unsigned long long mok = ballot64(ok_l);
+            const int snd = (int)((ballot64(first) >> el) & 1ull) ^ 1;
+            int pnum_lo = __builtin_amdgcn_readlane(__double2loint(rate_l), el);
+            int pnum_hi = __builtin_amdgcn_readlane(__double2hiint(rate_l), el);
+#else
             const bool first = a0 >= t;
             const unsigned long long mfirst = ballot64(first);
             const unsigned long long me = (mfirst | ballot64(ap >= t)) & 0xFFFFFFFFFFFFull;
@@ -380,6 +405,7 @@ void hop_q64_kernel(HopParams p)
                 pnum_lo = __builtin_amdgcn_readlane(__double2loint(rr.y), el);
                 pnum_hi = __builtin_amdgcn_readlane(__double2hiint(rr.y), el);
             }
+#endif
             // lowest set bit of me certified?  (scalar integer logic: as a bool the compiler rebuilds it per lane)
             unsigned long long cert = me & mok & (0ull - me) & ok_mask;
             asm("" : "+s"(cert));
