@@ -225,9 +225,6 @@ def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red
     eng.set_base_table(base512, kmc_amd.tables.dumbbell_rate())
     fold_ms = eng.last_kernel_ms()
     eng.fill_random(CONC, SEED)                              # ONE seed: streams are keyed by the global replica id
-    check = None
-    if keep_check:
-        check = dict(replica_ids=[offset + k for k in range(keep_check)], occ0=eng.get_lattice()[:keep_check].copy())
     eng.rates_full()
     eng.sync()
     rates_ms = eng.last_kernel_ms()
@@ -277,12 +274,9 @@ def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red
     n_span = min(args.steps, 64)
     ev = eng.run_kernel_times(64)[-n_span:]
     span_ms, groups = eng.run_span_ms(n_span)
-    if check is not None:
-        check.update(occ1=eng.get_lattice()[:keep_check].copy(), d_star=ds[:keep_check].copy(), time=sc['time'][:keep_check].copy(),
-                     presim_hops=hops_per_step, sim_hops=hops_per_step * (args.warmup + args.steps))
     out = dict(elapsed=elapsed, k_ms=span_ms / n_span, launch_ms=float(np.mean(ev)), groups=groups, R=R,
                n_exact=int(st['n_exact'].sum()), stopped=int((st['status'] != 0).sum()),
-               stats=ensemble.finalize(acc, [CONC])[0], fold_ms=fold_ms, rates_ms=rates_ms, check=check,
+               stats=ensemble.finalize(acc, [CONC])[0], fold_ms=fold_ms, rates_ms=rates_ms,
                hops_per_step=hops_per_step, base512=base512)
     if rccl is not None:
         eng.comm_destroy(rccl[1])
@@ -336,6 +330,26 @@ def measure_other(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torc
     return out
 
 
+def d_star_check_run(kmc_amd, np, local_rank, base512, n_replicas=4, sim_steps=40):
+    """"D* match vs CPU ref": the ensemble's first replicas (global ids 0 ..) run again in a small engine of their own --
+    the Philox streams are keyed by the global replica id, so these ARE the timed run's replicas over its first steps --
+    for 1 presimulation + sim_steps simulation steps; cpu_baseline() replays them with the C oracle.  (Kept apart from
+    the timed run so that its length does not grow with --steps: the oracle does 5e4 hops/s.)"""
+    hops_per_step = int(N_SIDE * N_SIDE * 1 * CONC)
+    with kmc_amd.KMCEngine(n_replicas, N_SIDE, N_SIDE, window_mode='hex_ref', device=local_rank) as eng:
+        eng.set_base_table(base512, kmc_amd.tables.dumbbell_rate())
+        eng.fill_random(CONC, SEED)
+        occ0 = eng.get_lattice()
+        eng.rates_full()
+        eng.run(hops_per_step, presim=True, seed=SEED)
+        eng.init_displacements()
+        for _ in range(sim_steps):
+            eng.run(hops_per_step, presim=False, seed=SEED)
+        ds, _, _ = eng.diffusion(CONC)
+        return dict(replica_ids=list(range(n_replicas)), occ0=occ0, occ1=eng.get_lattice(), d_star=ds, time=eng.scalars()['time'],
+                    presim_hops=hops_per_step, sim_hops=hops_per_step * sim_steps)
+
+
 def shard(total, rank, world):
     lo, hi = total * rank // world, total * (rank + 1) // world
     return hi - lo, lo
@@ -344,8 +358,8 @@ def shard(total, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=400)         # 1.5 s of timed region at 3.8 ms per step
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--replicas', type=int, default=ENSEMBLE, help='replicas per GPU (weak) / in total (strong)')
     ap.add_argument('--collective', choices=('torch', 'rccl'), default='torch',
@@ -429,8 +443,7 @@ def main():
         return
 
     R, offset = replicas_of(args.scaling)
-    m = measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red_dev,
-                keep_check=2 if rank == 0 and not args.no_cpu_baseline else 0)
+    m = measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red_dev, keep_check=0)
     other = None
     if world > 1:
         o_scaling = 'strong' if args.scaling == 'weak' else 'weak'
@@ -500,7 +513,7 @@ def main():
     if other is not None:
         out['other_scaling'] = other
     if not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(np, m['base512'], m['check'], host_threads())
+        out['cpu_baseline'] = cpu_baseline(np, m['base512'], d_star_check_run(kmc_amd, np, local_rank, m['base512']), host_threads())
     emit(out)
 
 
