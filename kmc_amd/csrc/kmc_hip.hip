@@ -37,6 +37,7 @@ struct kmc_ctx {
     bool lds64;            // 64 x 64 replicas: the specialised kernels of kmc_hop_lds64.h / kmc_hop_q64.h
     bool q64;              // ... the 16-replicas-per-CU kernel (kmc_hop_q64.h) rather than the 8-per-CU one
     bool q64_auto;         // what kmc_set_hop_kernel(ctx, 0) picks
+    bool qany_ok, qany;    // 8 <= nx, ny <= 64, not 64 x 64: hop_q64_kernel<., true> (the 16-per-CU layout at any size)
     void* xscratch;        // [R][Q64_XSCRATCH] exact-path scratch of hop_q64_kernel
     bool big_ok, use_big;  // larger lattices whose bitmaps fit LDS: kmc_hop_big.h (else kmc_hop_global.h)
     BigGeom geom;
@@ -693,7 +694,9 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     // within 2 % of each other (scripts/kernel_crossover.py), beyond it wins by up to 1.5x.
     c->q64_auto = true;
     c->q64 = c->lds64 && c->q64_auto;
-    if (c->lds64) CREATE_CHK(hipMalloc(&c->xscratch, (size_t)c->R * Q64_XSCRATCH));
+    c->qany_ok = c->lds_path && !c->lds64 && nx >= 8 && ny >= 8;
+    c->qany = c->qany_ok;
+    if (c->lds64 || c->qany_ok) CREATE_CHK(hipMalloc(&c->xscratch, (size_t)c->R * Q64_XSCRATCH));
     if (c->lds_path) {
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, K64_LDS_BYTES));
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, K64_LDS_BYTES));
@@ -821,16 +824,19 @@ int kmc_uses_lds_path(kmc_ctx* c) { return c && c->lds_path ? 1 : 0; }
 int kmc_lds_bytes(kmc_ctx* c)
 {
     if (!c || !c->lds_path) return 0;
+    if (c->qany) return Q64_LDS_BYTES;
     return c->lds64 ? (c->q64 ? Q64_LDS_BYTES : K64_LDS_BYTES) : (int)host_hop_lds_bytes(c->nx, c->n);
 }
 
 // which = 0: the default kernel for the lattice size and replica count; 1: the generic kernel (any size);
-// 2 / 3: for 64 x 64 replicas, the 8-replicas-per-CU kernel (kmc_hop_lds64.h) / the 16-per-CU one (kmc_hop_q64.h)
+// 2 / 3: for 64 x 64 replicas, the 8-replicas-per-CU kernel (kmc_hop_lds64.h) / the 16-per-CU one (kmc_hop_q64.h);
+// 4: the 16-per-CU layout for lattices of 8 .. 64 rows and columns other than 64 x 64 (the default there)
 int kmc_set_hop_kernel(kmc_ctx* c, int which)
 {
     CTXCHK(c);
-    if (which < 0 || which > 3) return fail(c, KMC_EINVAL, "kmc_set_hop_kernel: which must be 0, 1, 2 or 3");
-    c->lds64 = c->lds_path && c->nx == 64 && c->ny == 64 && which != 1;
+    if (which < 0 || which > 4) return fail(c, KMC_EINVAL, "kmc_set_hop_kernel: which must be 0 ... 4");
+    c->lds64 = c->lds_path && c->nx == 64 && c->ny == 64 && which != 1 && which != 4;
+    c->qany = c->qany_ok && (which == 4 || which == 0);
     c->q64 = c->lds64 && (which == 3 || (which == 0 && c->q64_auto));
     c->use_big = c->big_ok && which != 1;
     return KMC_OK;
@@ -1254,7 +1260,7 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     // 16 replicas fit a CU and there are more than the 3-wave build holds at once (12 per CU): the 4-waves-per-SIMD
     // build; below that its spills only cost (a single 30 x 30 lattice: -4 %)
     const bool gen_w4 = gen_lds * 16 <= 160 * 1024 && c->R > 256 * 12;
-    const int per_cu = c->lds64 ? (c->q64 ? 16 : 8) : (gen_w4 ? 16 : (gen_lds * 12 <= 160 * 1024 ? 12 : (int)((160 * 1024) / gen_lds)));
+    const int per_cu = c->qany ? 16 : c->lds64 ? (c->q64 ? 16 : 8) : (gen_w4 ? 16 : (gen_lds * 12 <= 160 * 1024 ? 12 : (int)((160 * 1024) / gen_lds)));
     const bool split = c->R >= 2 * 8 && (c->split == 2 || (c->split == 0 && c->R > 192 * per_cu));
     const int r_half = ((c->R / 2 + 7) / 8) * 8;             // multiples of 8: blocks go round the 8 XCDs
     if (counts && c->R > 1) {
@@ -1290,7 +1296,11 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
             hipStream_t gs = c->gstream[g];
             if (g == 0) hipEventRecord(c->ev0, gs);
             HIPCHK(c, hipEventRecord(c->run_ev[slot][g][0], gs));
-            if (c->lds64 && c->q64 && c->have_compact)
+            if (c->qany && c->have_compact)
+                hop_q64_kernel<true, true><<<rg, 64, Q64_LDS_BYTES, gs>>>(p);
+            else if (c->qany)
+                hop_q64_kernel<false, true><<<rg, 64, Q64_LDS_BYTES, gs>>>(p);
+            else if (c->lds64 && c->q64 && c->have_compact)
                 hop_q64_kernel<true><<<rg, 64, Q64_LDS_BYTES, gs>>>(p);
             else if (c->lds64 && c->q64)
                 hop_q64_kernel<false><<<rg, 64, Q64_LDS_BYTES, gs>>>(p);
@@ -1319,10 +1329,15 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     time_begin(c);
     HIPCHK(c, hipEventRecord(c->run_ev[slot][0][0], c->stream));
 #ifdef Q64_FORCE_DENSE          // scripts/variants.py: A/B of the pair tables against the dense table
-    if (false)
+    const bool q_compact = false;
 #else
-    if (c->lds64 && c->q64 && c->have_compact)
+    const bool q_compact = c->have_compact;
 #endif
+    if (c->qany && q_compact)
+        hop_q64_kernel<true, true><<<c->R, 64, Q64_LDS_BYTES, c->stream>>>(p);
+    else if (c->qany)
+        hop_q64_kernel<false, true><<<c->R, 64, Q64_LDS_BYTES, c->stream>>>(p);
+    else if (c->lds64 && c->q64 && q_compact)
         hop_q64_kernel<true><<<c->R, 64, Q64_LDS_BYTES, c->stream>>>(p);
     else if (c->lds64 && c->q64)
         hop_q64_kernel<false><<<c->R, 64, Q64_LDS_BYTES, c->stream>>>(p);

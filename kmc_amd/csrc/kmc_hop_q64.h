@@ -117,12 +117,36 @@ __device__ __noinline__ void exact_select_q64(const unsigned char* smem, const d
     exact_select_par_impl<1, 2, true>([=](long s) -> uint32_t { return q64_key(klo, khp, (int)s); }, table, 4096, rho, sh);
 }
 
-template <bool COMPACT>
+// The same for an nx x ny lattice kept in the 64-column layout (ANY, below): the reference's entry order is
+// row-major over nx x ny, the planes are indexed by row * 64 + column.
+__device__ __noinline__ void exact_select_qany(const unsigned char* smem, const double* table, int ny, int n, double rho,
+                                               ExactParShared* sh)
+{
+    const uint16_t* klo = reinterpret_cast<const uint16_t*>(smem + Q64_KLO);
+    const uint32_t* khp = reinterpret_cast<const uint32_t*>(smem + Q64_KHP);
+    exact_select_par_impl<1, 2, true>([=](long s) -> uint32_t {
+        const int i = (int)s / ny, j = (int)s - i * ny;
+        return q64_key(klo, khp, i * 64 + j);
+    }, table, n, rho, sh);
+}
+
+// ANY = false: 64 x 64, every wrap is a mask, the instantiation the headline number is measured on.
+// ANY = true: any 8 <= nx, ny <= 64 in the SAME 10 KB layout (rows and columns beyond the lattice hold the all-Li
+// key, whose rates are zero, and are never selected), so that ensembles of small lattices -- the reference's
+// D-against-size study, Mc_Lattice.py:243-258 -- also run 16 to a CU with two-entries-per-lane pair gathers.
+// What changes: wraps are compare-and-add; the halo columns mirror columns 0, 1 at ny, ny + 1 and ny - 2, ny - 1
+// at -2, -1; a column's bitmap carries rows 0..3 again at bits nx .. nx + 3 (what the five-row read at
+// (row - 2) mod nx reaches); a window that wraps round a lattice whose width is not a multiple of 16 can touch a
+// third quarter; site numbers in memory (trace, tags, keys) are row * ny + column.
+template <bool COMPACT, bool ANY = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Q64_WAVES_PER_SIMD, Q64_WAVES_PER_SIMD)))
 void hop_q64_kernel(HopParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int r = p.order ? p.order[blockIdx.x + p.r_base] : (int)blockIdx.x + p.r_base, lane = threadIdx.x;
+    const int nx = ANY ? p.nx : 64, ny = ANY ? p.ny : 64;
+    // site number in memory of the site at (row s >> 6, column s & 63) of the 64-column layout
+    auto ext = [&](int s) -> int { return ANY ? (s >> 6) * ny + (s & 63) : s; };
 #if defined(KMC_STAMPS) && KMC_STAMPS == 2
     const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -132,9 +156,10 @@ void hop_q64_kernel(HopParams p)
     uint32_t* colw = reinterpret_cast<uint32_t*>(smem + Q64_COL);
 #define Q64_XSH (reinterpret_cast<ExactParShared*>(reinterpret_cast<unsigned char*>(QP->xscratch) + (size_t)r * Q64_XSCRATCH))
 
-#define Q64_OCC_G (QP->occ + (size_t)r * 4096)
-#define Q64_KEYS_G (QP->keys + (size_t)r * 4096)
-#define Q64_TAGS_G (QP->tags + (size_t)r * 4096)
+#define Q64_N_SITES (ANY ? (size_t)QP->n : (size_t)4096)
+#define Q64_OCC_G (QP->occ + (size_t)r * Q64_N_SITES)
+#define Q64_KEYS_G (QP->keys + (size_t)r * Q64_N_SITES)
+#define Q64_TAGS_G (QP->tags + (size_t)r * Q64_N_SITES)
     const unsigned char* __restrict__ wsum_b = reinterpret_cast<const unsigned char*>(p.wsum);
     const unsigned char* __restrict__ table_b = reinterpret_cast<const unsigned char*>(p.table);
     auto load_w = [&](uint32_t k) -> double {
@@ -146,23 +171,32 @@ void hop_q64_kernel(HopParams p)
     uint64_t cb = 0;                       // lane j owns column j's bitmap
     {
         const uint8_t* occ_g = Q64_OCC_G;
-        for (int i = 0; i < 64; ++i) cb |= (uint64_t)(occ_g[i * 64 + lane] & 1u) << i;
+        if (ANY) {
+            if (lane < ny)
+                for (int i = 0; i < nx; ++i) cb |= (uint64_t)(occ_g[i * ny + lane] & 1u) << i;
+            if (nx < 64) cb |= (cb & 15ull) << nx;          // rows 0..3 again above row nx - 1
+        } else {
+            for (int i = 0; i < 64; ++i) cb |= (uint64_t)(occ_g[i * 64 + lane] & 1u) << i;
+        }
     }
-    // column c lives at dword 3 * (c + 2); columns 0, 1 are mirrored at 64, 65 and 62, 63 at -2, -1
-    const bool col_mirrored = lane < 2 || lane >= 62;
+    // column c lives at dword 3 * (c + 2); columns 0, 1 are mirrored at ny, ny + 1 and ny - 2, ny - 1 at -2, -1
+    const bool col_mirrored = ANY ? (lane < 2 || (lane >= ny - 2 && lane < ny)) : (lane < 2 || lane >= 62);
     auto write_col = [&]() {
         const uint32_t lo = (uint32_t)cb, hi = (uint32_t)(cb >> 32);
+        // third dword = bits 64 .. 95 of the periodic bitmap: rows 64 - nx .. (read only when nx + 3 >= 64)
+        const uint32_t lo3 = ANY ? lo >> ((64 - nx) & 31) : lo;
         // the addresses are recomputed from the lane number on every call (one multiply-add): hoisted
         // out of the hop loop they are spilled to scratch memory at the 128-register limit
         int ln = lane;
         asm volatile("" : "+v"(ln));
         typedef __attribute__((address_space(3))) uint32_t lds_u32;
         lds_u32* cp = (lds_u32*)(uintptr_t)(lds_base + (uint32_t)Q64_COL + 12u * (uint32_t)(ln + 2));
-        cp[0] = lo; cp[1] = hi; cp[2] = lo;
+        cp[0] = lo; cp[1] = hi; cp[2] = lo3;
         if (col_mirrored) {
             // halo columns 66, 67 (lanes 0, 1) and 0, 1 (lanes 62, 63)
-            lds_u32* mp = (lds_u32*)(uintptr_t)(lds_base + (uint32_t)Q64_COL + 12u * (uint32_t)((ln + 66) & 127));
-            mp[0] = lo; mp[1] = hi; mp[2] = lo;
+            const uint32_t mc = ANY ? (uint32_t)(ln < 2 ? ln + ny + 2 : ln - ny + 2) : (uint32_t)((ln + 66) & 127);
+            lds_u32* mp = (lds_u32*)(uintptr_t)(lds_base + (uint32_t)Q64_COL + 12u * mc);
+            mp[0] = lo; mp[1] = hi; mp[2] = lo3;
         }
     };
     write_col();
@@ -170,7 +204,9 @@ void hop_q64_kernel(HopParams p)
     wave_fence();
     const uint32_t* keys_in = Q64_KEYS_G;
     for (int s = lane; s < 4096; s += KMC_WAVE) {
-        uint32_t k = keys_in[s];
+        uint32_t k;
+        if (ANY) k = ((s >> 6) < nx && lane < ny) ? keys_in[(s >> 6) * ny + lane] : Q64_VAC;     // s & 63 == lane
+        else k = keys_in[s];
         k = k > 0x3FFFFu ? Q64_VAC : k;    // KMC_VACANT (0xFFFFFFFF) -> all neighbours Li (zero row)
         klo[s] = (uint16_t)k;
         atomicOr(&khp[s >> 4], (k >> 16) << ((s & 15) * 2));
@@ -299,11 +335,12 @@ void hop_q64_kernel(HopParams p)
             need_exact = false;
             wave_fence();
             ExactParShared* xsh = Q64_XSH;
-            exact_select_q64(smem, QP->table, readlane_f64(rho_v, 0), xsh);
+            if (ANY) exact_select_qany(smem, QP->table, ny, QP->n, readlane_f64(rho_v, 0), xsh);
+            else exact_select_q64(smem, QP->table, readlane_f64(rho_v, 0), xsh);
             wave_fence();
             ++n_exact;
             if (!(xsh->gamma > 0.0)) { status = 2; run = 0; }
-            else if (xsh->idx >= 6L * 4096) { status = 1; run = 0; }
+            else if (xsh->idx >= 6L * (long)Q64_N_SITES) { status = 1; run = 0; }
             else {
                 ex_have = true;
                 // rho <= 0 selects entry 0 whatever its rate (searchsorted left, B4): such a hop may leave a
@@ -425,8 +462,13 @@ void hop_q64_kernel(HopParams p)
                 const double g = xsh->gamma;
                 const double pn = xsh->c_found / g - xsh->cprev_found / g;      // the reference's own expression (:497)
                 d = (int)(ex_idx % 6);
-                j = (int)((ex_idx / 6) & 63);
-                i_sel = (int)((ex_idx / 6) >> 6);
+                if (ANY) {
+                    i_sel = (int)(ex_idx / 6) / ny;
+                    j = (int)(ex_idx / 6) - i_sel * ny;
+                } else {
+                    j = (int)((ex_idx / 6) & 63);
+                    i_sel = (int)((ex_idx / 6) >> 6);
+                }
                 pnum_lo = __builtin_amdgcn_readfirstlane(__double2loint(pn));
                 pnum_hi = __builtin_amdgcn_readfirstlane(__double2hiint(pn));
                 exact_flag = 1 << 30;
@@ -434,12 +476,13 @@ void hop_q64_kernel(HopParams p)
             KMC_STAMP(2);
             const int ii = i_sel;
             const int s_src = ii * 64 + j;
-            const int idx = s_src * 6 + d;
+            const int idx = (ANY ? ii * ny + j : s_src) * 6 + d;
             // ---- update (:518-535) -------------------------------------------
             const int di = ((2310 >> (2 * d)) & 3) - 1;          // {1, 0, -1, -1, 0, 1}
             const int dj = ((105 >> (2 * d)) & 3) - 1;           // {0, 1, 1, 0, -1, -1}
             const int ie = ii + di, je = j + dj;                 // unwrapped
-            const int iw = ie & 63, jw = je & 63;
+            const int iw = ANY ? (ie < 0 ? ie + nx : (ie >= nx ? ie - nx : ie)) : (ie & 63);
+            const int jw = ANY ? (je < 0 ? je + ny : (je >= ny ? je - ny : je)) : (je & 63);
             const int s_dst = iw * 64 + jw;
             KMC_STAMP(6);
             // ---- window geometry (:444-453): group a = window row a; its lane c holds sites c and
@@ -447,26 +490,43 @@ void hop_q64_kernel(HopParams p)
             const int min_di = di < 0 ? di : 0, min_dj = dj < 0 ? dj : 0;
             const int i_lo = ii - 2 + (wm_ext & min_di), n_i = wm_ni0 + (wm_ext & di & 1);     // scalar integer ops only
             const int j_lo = j - 2 + (wm_ext & min_dj), n_j = wm_nj0 + (wm_ext & dj & 1);
-            const int si = (i_lo + grp_a) & 63;
+            int si;                                              // this group's lattice row
+            if (ANY) { si = i_lo + grp_a; si = si < 0 ? si + nx : (si >= nx ? si - nx : si); }
+            else si = (i_lo + grp_a) & 63;
             const bool act = grp_a < n_i;
-            const int qa = (j_lo & 63) >> 4, qb = ((j_lo + n_j - 1) & 63) >> 4;
+            int qa, qb, qc = 0;
+            bool three = false;                                  // ANY: a window that wraps past a partial last quarter
+            if (ANY) {
+                const int ja = j_lo < 0 ? j_lo + ny : j_lo, je_ = j_lo + n_j - 1, jb = je_ >= ny ? je_ - ny : je_;
+                qa = ja >> 4; qb = jb >> 4; qc = (ny - 1) >> 4;
+                three = ja > jb && qc != qa;                     // then qb = 0 and the quarters are qa < qc and 0
+            } else {
+                qa = (j_lo & 63) >> 4; qb = ((j_lo + n_j - 1) & 63) >> 4;
+            }
             const bool two = qa != qb;                           // uniform
             // two single-lane updates under exec masks (the empty asm keeps them branches: as selects they
             // cost four moves and four selects more)
             // (clear / set, not flips: with rho == 0 the reference "hops" entry 0 whatever its rate, B4, so the
             // source may be vacant already and the destination occupied)
-            if (lane == j) { asm volatile(""); cb &= ~(1ull << ii); }
-            if (lane == jw) { asm volatile(""); cb |= 1ull << iw; }
+            unsigned long long bit_src = 1ull << ii, bit_dst = 1ull << iw;
+            if (ANY) {                                           // rows 0..3 again at bits nx .. nx + 3
+                if (ii < 4 && ii + nx < 64) bit_src |= 1ull << (ii + nx);
+                if (iw < 4 && iw + nx < 64) bit_dst |= 1ull << (iw + nx);
+            }
+            if (lane == j) { asm volatile(""); cb &= ~bit_src; }
+            if (lane == jw) { asm volatile(""); cb |= bit_dst; }
             if (lane == j || lane == jw) write_col();
             wave_fence();
             KMC_STAMP(7);
             // ---- windowed refresh (:453-465): this lane's window column is the one = c (mod 8)
-            const int wcol = (grp_c - j_lo) & 7;
-            const int sj = (j_lo + wcol) & 63;
+            const int wcol = ANY ? grp_c : (grp_c - j_lo) & 7;
+            int sj;
+            if (ANY) { sj = j_lo + wcol; sj = sj < 0 ? sj + ny : (sj >= ny ? sj - ny : sj); }
+            else sj = (j_lo + wcol) & 63;
             const bool inw = act & (wcol < n_j);
             uint32_t knew;
             {
-                const int st = (si - 2) & 63;
+                const int st = ANY ? (si < 2 ? si - 2 + nx : si - 2) : (si - 2) & 63;
                 // columns sj-2 .. sj+2 are halo columns sj .. sj+4; +1 dword selects the rotated view
                 const uint32_t ca = lds_base + (uint32_t)(Q64_COL + sj * 12 + (st >> 5) * 4);   // LDS byte address
                 const uint32_t sh = (uint32_t)st & 31u;
@@ -509,8 +569,9 @@ void hop_q64_kernel(HopParams p)
             // instead of ~10 vector instructions deciding which of the lane's keys the window replaced.
             // Lanes of rows outside the window keep whatever their registers hold: their sums are not used.
             wave_fence();
-            double wA0, wA1, wB0, wB1;
+            double wA0, wA1, wB0, wB1, wC0, wC1;
             asm("" : "=v"(wA0), "=v"(wA1), "=v"(wB0), "=v"(wB1));
+            if (ANY) asm("" : "=v"(wC0), "=v"(wC1));
             if (act) {
                 const int sA = si * 64 + qa * 16 + grp_c;
                 const uint32_t hwA = khp[si * 4 + qa];
@@ -525,6 +586,14 @@ void hop_q64_kernel(HopParams p)
                     wB1 = load_w((uint32_t)klo[sB + 8] | (__builtin_amdgcn_ubfe(hwB, 2u * grp_c + 16u, 2u) << 16));
                 }
             }
+            if (ANY && three) {
+                if (act) {
+                    const int sC = si * 64 + qc * 16 + grp_c;
+                    const uint32_t hwC = khp[si * 4 + qc];
+                    wC0 = load_w((uint32_t)klo[sC] | (__builtin_amdgcn_ubfe(hwC, 2u * grp_c, 2u) << 16));
+                    wC1 = load_w((uint32_t)klo[sC + 8] | (__builtin_amdgcn_ubfe(hwC, 2u * grp_c + 16u, 2u) << 16));
+                }
+            }
             // ---- book-keeping that nothing in this hop waits for runs while the gathers are in flight
             writelane5(gam_lo, gam_hi, pn_lo, pn_hi, idx_v, __double2loint(gamma), __double2hiint(gamma),
                        pnum_lo, pnum_hi, idx | exact_flag, hl);
@@ -532,7 +601,8 @@ void hop_q64_kernel(HopParams p)
             // tag move (:521-528): registers only, memory is touched at the chunk flush
             if (!presim) {
                 const unsigned long long m = ballot64((tg_sv & 0xFFFF) == s_src);
-                const int wrap = ((ie >> 6) << 8) + ((je >> 6) << 16);      // floor(ie / 64) = -1, 0, +1
+                const int wrap = ANY ? ((ie < 0 ? -1 : (ie >= nx ? 1 : 0)) << 8) + ((je < 0 ? -1 : (je >= ny ? 1 : 0)) << 16)
+                                     : ((ie >> 6) << 8) + ((je >> 6) << 16);      // floor(ie / 64) = -1, 0, +1
                 // One straight line for both cases (a taken branch costs a wave ~27 cycles, a not-taken one ~11:
                 // scripts/probes/valu_rate_probe.hip): the atom either came with an earlier hop of this chunk (its
                 // lane lm keeps the site it entered the chunk from and gathers the wrap) or its tag is still in
@@ -548,9 +618,11 @@ void hop_q64_kernel(HopParams p)
             KMC_STAMP(4);
             {
                 // from group a to the lane that owns row i_lo + a
-                const int rel = (lane - i_lo) & 63;
+                int rel;
+                if (ANY) { rel = lane - i_lo; rel = rel < 0 ? rel + nx : (rel >= nx ? rel - nx : rel); }
+                else rel = (lane - i_lo) & 63;
                 const int src = (rel & 7) << 5;                  // byte address of lane 8 * rel
-                const bool take = rel < n_i;
+                const bool take = ANY ? (rel < n_i) & (lane < nx) : rel < n_i;
                 const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(sumA));
                 const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(sumA));
                 const double nA = __hiloint2double(hi, lo);
@@ -567,6 +639,15 @@ void hop_q64_kernel(HopParams p)
                     if (qb == 1) { asm volatile(""); Q1 = take ? nB : Q1; }
                     if (qb == 2) { asm volatile(""); Q2 = take ? nB : Q2; }
                     if (qb == 3) { asm volatile(""); Q3 = take ? nB : Q3; }
+                }
+                if (ANY && three) {
+                    const double sumC = group8_sum(wC0 + wC1);
+                    const int loc = __builtin_amdgcn_ds_bpermute(src, __double2loint(sumC));
+                    const int hic = __builtin_amdgcn_ds_bpermute(src, __double2hiint(sumC));
+                    const double nC = __hiloint2double(hic, loc);
+                    if (qc == 1) { asm volatile(""); Q1 = take ? nC : Q1; }     // qa < qc, so qc is 1, 2 or 3
+                    if (qc == 2) { asm volatile(""); Q2 = take ? nC : Q2; }
+                    if (qc == 3) { asm volatile(""); Q3 = take ? nC : Q3; }
                 }
             }
             wave_fence();
@@ -595,15 +676,15 @@ void hop_q64_kernel(HopParams p)
             int4* tags_g = Q64_TAGS_G;
             const bool used = (tg_used >> lane) & 1ull;
             int4 tv = make_int4(0, 0, 0, 0);
-            if (used) tv = tags_g[tg_vac];
+            if (used) tv = tags_g[ext(tg_vac)];
             // the site an atom left is vacant now unless a moved atom sits on it, i.e. unless it is occupied:
             // one read of the column bitmaps
             const uint32_t hw = colw[3 * ((tg_vac & 63) + 2) + ((tg_vac >> 11) & 1)];
             const bool home_empty = ((hw >> ((tg_vac >> 6) & 31)) & 1u) == 0u;
             tv.z += ((tg_ow >> 8) & 255) - 64;
             tv.w += ((tg_ow >> 16) & 255) - 64;
-            if (used) tags_g[tg_site] = tv;
-            if (used && home_empty) tags_g[tg_vac] = make_int4(-1, 0, 0, 0);
+            if (used) tags_g[ext(tg_site)] = tv;
+            if (used && home_empty) tags_g[ext(tg_vac)] = make_int4(-1, 0, 0, 0);
             tg_sv = -1;
         }
         const double gam_v = __hiloint2double(gam_hi, gam_lo), pn_v = __hiloint2double(pn_hi, pn_lo);
@@ -648,10 +729,18 @@ void hop_q64_kernel(HopParams p)
 #endif
     uint8_t* occ_g = Q64_OCC_G;
     uint32_t* keys_g = Q64_KEYS_G;
-    for (int i = 0; i < 64; ++i) occ_g[i * 64 + lane] = (uint8_t)((cb >> i) & 1ull);
-    for (int s = lane; s < 4096; s += KMC_WAVE) {
-        // site s = (row s >> 6, column lane): its occupancy is a bit of this lane's own bitmap
-        keys_g[s] = ((cb >> (s >> 6)) & 1ull) ? q64_key(klo, khp, s) : KMC_VACANT;
+    if (ANY) {
+        if (lane < ny)
+            for (int i = 0; i < nx; ++i) {
+                occ_g[i * ny + lane] = (uint8_t)((cb >> i) & 1ull);
+                keys_g[i * ny + lane] = ((cb >> i) & 1ull) ? q64_key(klo, khp, i * 64 + lane) : KMC_VACANT;
+            }
+    } else {
+        for (int i = 0; i < 64; ++i) occ_g[i * 64 + lane] = (uint8_t)((cb >> i) & 1ull);
+        for (int s = lane; s < 4096; s += KMC_WAVE) {
+            // site s = (row s >> 6, column lane): its occupancy is a bit of this lane's own bitmap
+            keys_g[s] = ((cb >> (s >> 6)) & 1ull) ? q64_key(klo, khp, s) : KMC_VACANT;
+        }
     }
     if (lane < 6) QP->hist[r * 6 + lane] += hist_l[lane];
     const double b_stat = lane < 5 ? bstat_l[lane] : 0.0;

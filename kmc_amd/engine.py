@@ -283,9 +283,10 @@ class KMCEngine:
         return bool(self._lib.kmc_table_is_compact(self._ctx))
 
     def set_hop_kernel(self, generic=False, which=None):
-        """Choose the hop kernel (tests): generic=True the any-size kernel; for 64 x 64 replicas which=2 the
-        8-replicas-per-CU kernel (kmc_hop_lds64.h), which=3 the 16-per-CU one (kmc_hop_q64.h); which=0 the
-        default (3)."""
+        """Choose the hop kernel (tests): generic=True / which=1 the any-size kernel with block sums in LDS; for
+        64 x 64 replicas which=2 the 8-replicas-per-CU kernel (kmc_hop_lds64.h), which=3 the 16-per-CU one
+        (kmc_hop_q64.h); which=4 the 16-per-CU layout for 8 ... 64 rows and columns other than 64 x 64; which=0 the
+        default (3 at 64 x 64, 4 where it applies)."""
         self._chk(self._lib.kmc_set_hop_kernel(self._ctx, int(which) if which is not None else int(bool(generic))))
 
     def set_debug(self, force_exact=False, margin_scale=1.0):

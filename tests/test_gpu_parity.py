@@ -200,9 +200,11 @@ def test_golden_trajectory(kmc, tables, dense, dense_master, path, force_exact):
 
 
 @pytest.mark.parametrize('force_exact', [False, True], ids=['certified', 'exact'])
-@pytest.mark.parametrize('name,which', [('n64_x05', 1), ('n64_x05', 2), ('n64_x05', 3), ('n30_x05_master', 1),
+@pytest.mark.parametrize('name,which', [('n64_x05', 1), ('n64_x05', 2), ('n64_x05', 3), ('n30_x05_master', 1), ('n30_x05_master', 4),
+                                        ('n30_x05', 1), ('n30_x05', 4), ('n8x12_x05', 4),
                                         ('n70x66_x04_master', 0), ('n70x66_x04_master', 1)],
-                         ids=['n64-generic', 'n64-lds64', 'n64-q64', 'n30master-generic', 'n70x66master-big', 'n70x66master-global'])
+                         ids=['n64-generic', 'n64-lds64', 'n64-q64', 'n30master-generic', 'n30master-q', 'n30-generic', 'n30-q', 'n8x12-q',
+                              'n70x66master-big', 'n70x66master-global'])
 def test_reference_trajectory_every_kernel_family(kmc, tables, dense, dense_master, name, which, force_exact):
     """The reference-generated trajectories at BASELINE's lattice sizes through EVERY hop kernel that can take them
     (kmc_set_hop_kernel), certified and with every hop forced through the exact replay: selections, lattice, tags,
@@ -247,6 +249,15 @@ def _oracle_run(occ, dense, mode, draws_pre, draws_sim, conc):
     (64, 33, 4, 400, 1200, 'hex_ref', 1.0),
     (5, 5, 4, 100, 400, 'hex_ref', 1.0),
     (6, 64, 4, 100, 600, 'full', 1.0),
+    # the 16-per-CU layout at any size (hop_q64_kernel<., true>): a width that is no multiple of 16 (a window that wraps
+    # touches three quarters), 61 ... 63 rows (the bitmap's third dword is read), the smallest lattice it takes
+    (62, 35, 4, 600, 1500, 'hex_ref', 1.0),
+    (63, 17, 3, 400, 1200, 'full', 1.0),
+    (61, 34, 3, 400, 1200, 'obj_ref', 1.0),
+    (8, 8, 4, 100, 500, 'hex_ref', 1.0),
+    (9, 61, 3, 200, 800, 'obj_ref', 1.0),
+    (40, 20, 3, 300, 900, 'full', 1.0),
+    (35, 62, 3, 400, 1200, 'hex_ref', 3e7),
     # inflated margin: a few percent of the hops take the exact path, mixed in
     (30, 30, 4, 600, 1500, 'hex_ref', 3e7),
     (64, 64, 2, 100, 300, 'hex_ref', 1.5e6),
@@ -259,8 +270,9 @@ def test_random_ensemble_vs_oracle(kmc, tables, dense, cfg):
     d_pre = np.stack([rs.rand(R, hp), np.ones((R, hp))], axis=-1)
     d_sim = rs.rand(R, hs, 2)
     oracle = [_oracle_run(occ[r], dense, mode, d_pre[r], d_sim[r], conc[r]) for r in range(R)]
-    # 64 x 64 has two kernels (16 replicas per CU, the default, and 8): both
-    for which in ((3, 2) if (nx, ny) == (64, 64) else (0,)):
+    # 64 x 64 has two kernels (16 replicas per CU, the default, and 8): both; 8 ... 64 rows and columns: the 16-per-CU
+    # layout (the default) and the any-size kernel with block sums in LDS
+    for which in ((3, 2) if (nx, ny) == (64, 64) else ((4, 1) if min(nx, ny) >= 8 else (0,))):
         _ensemble_vs_oracle(kmc, tables, cfg, which, occ, d_pre, d_sim, oracle)
 
 
