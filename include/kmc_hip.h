@@ -148,7 +148,10 @@ int kmc_get_status(kmc_ctx* ctx, int32_t* status, int64_t* hops_done, int64_t* n
 /* np.sum(hop_probability_matrix) with numpy's own association (:486), per replica */
 int kmc_gamma_exact(kmc_ctx* ctx, double* gamma /* [R] */);
 /* testing knobs: force_exact != 0 resolves every hop by the exact sequential
- * path; margin_scale multiplies the certification margin (default 1). */
+ * path (2: the large-lattice kernel may use the replay's short form, which skips
+ * the np.sum pass when the index does not depend on it -- what it does for the
+ * hops it cannot certify; 1: always the long form); margin_scale multiplies the
+ * certification margin (default 1). */
 int kmc_set_debug(kmc_ctx* ctx, int force_exact, double margin_scale);
 
 /* ---- observables (rows D1, D2) ----------------------------------------- */

@@ -140,9 +140,28 @@ __device__ __forceinline__ long long wave_scan_incl_i64(long long x)
 // Result in sh->idx, sh->gamma, sh->c_found, sh->cprev_found (every thread may read them after the
 // call; the call ends with a barrier).  keys: KMC_VACANT = vacant; table must have the all-zero row
 // 0x7FFFF (kmc_create allocates 2^19 rows for that).
-template <int NW, int KMC_XP_SITES, bool LEAN, class KeyFn>     // KMC_XP_SITES = sites per thread and tile
+//
+// gamma_hint > 0 (the large-lattice kernel): skip the np.sum pass when the answer does not depend on it.  The caller's
+// own sum gamma_hint and G = np.sum(P) both lie within delta / 2 (relative) of the real sum -- delta is the caller's bound,
+// the "6n / 8192 + 512" term of its certification margin -- so with t = rho * gamma_hint
+//     c >= t (1 + delta)  implies  c / G >= rho                  hence fl(c / G) >= rho, and
+//     c <  t (1 - delta)  implies  c / G < rho (1 - u)           hence fl(c / G) <  rho  (delta carries 8 u of slack).
+// The sequential cumsum is replayed exactly as always and stopped at the first k with c_k >= T_hi = t (1 + delta); if
+// c_(k-1) < T_lo = t (1 - delta), every earlier entry fails the reference's test whatever G is, and k is the reference's
+// index: two thirds of the work (all of np.sum's pass, which cannot stop early) are saved.  Otherwise (an entry
+// inside the 2 delta band: ~1e-7 of the calls at 1024 x 1024) the function starts over with np.sum.  In the short
+// form sh->gamma is gamma_hint, not np.sum's bits: the caller's barrier diagnostic (S5) of such a hop is good to ~1e-9.
+//
+// STRIPED (the large-lattice kernel): a tile without an event needs only the TOTAL of its integer quanta, whatever thread
+// holds which entry.  So the tile is first read striped -- consecutive lanes take consecutive 16-byte pieces (two entries) of
+// the rate rows, three lanes to a site: the three pieces of a row arrive with one or two cache-line look-ups instead of
+// three, and the replay is bound by exactly those (one CU takes ~0.5 scattered 16-byte requests per cycle) -- and summed;
+// only a tile that holds an event (a binade crossing, a tie, the stop: ~60 of the 1000 tiles of a 1024 x 1024 replay) is
+// read again in the owner layout below, where every thread holds consecutive entries and the event's place can be found.
+template <int NW, int KMC_XP_SITES, bool LEAN, bool STRIPED = false, class KeyFn>     // KMC_XP_SITES = sites per thread and tile
 __device__ __forceinline__ void exact_select_par_impl(KeyFn keys, const double* __restrict__ table,
-                                                      int n, double rho, ExactParShared* sh)
+                                                      int n, double rho, ExactParShared* sh,
+                                                      double gamma_hint = 0.0, double delta = 0.0)
 {
     constexpr int XP_THREADS = 64 * NW;
     constexpr long XP_TILE = (long)XP_THREADS * KMC_XP_SITES * 6;
@@ -159,7 +178,9 @@ __device__ __forceinline__ void exact_select_par_impl(KeyFn keys, const double* 
     const long n6 = 6L * n;
     const long nfull = n6 / 8192;
     double total = 0.0;                                   // meaningful in thread 0
-    for (long c0 = 0; c0 < nfull; c0 += NW) {
+    bool fast = gamma_hint > 0.0 && rho > 0.0;            // uniform
+restart:
+    for (long c0 = 0; c0 < nfull && !fast; c0 += NW) {
         const long c = c0 + wv;
         if (c < nfull) {
             const long lo = c * 8192 + (long)lane * 128;
@@ -179,13 +200,20 @@ __device__ __forceinline__ void exact_select_par_impl(KeyFn keys, const double* 
             for (int q = 0; q < NW && c0 + q < nfull; ++q) total = total + sh->chunk_sum[q];
         __syncthreads();
     }
+    double t_lo = 0.0;                                    // fast form: the lower edge of the band (thread 0)
     if (tid == 0) {
         const long tail = n6 - nfull * 8192;
-        if (tail > 0) total = total + np_pairwise(nfull * 8192, tail, entry, sh->frames);
+        if (fast) total = gamma_hint;
+        else if (tail > 0) total = total + np_pairwise(nfull * 8192, tail, entry, sh->frames);
         sh->gamma = total;
         sh->done = 0; sh->idx = n6; sh->c = 0.0; sh->pos = 0; sh->c_found = 0.0; sh->cprev_found = 0.0;
         sh->cstar = 0.0;
-        if (!(total > 0.0)) {
+        if (fast) {
+            const double t = rho * total;
+            sh->cstar = ulp_step(t + t * delta, +1);
+            t_lo = ulp_step(t - t * delta, -1);
+            if (!(t_lo > 0.0)) sh->done = 3;               // rho * gamma underflows: the long form decides
+        } else if (!(total > 0.0)) {
             sh->done = 1;                                  // gamma == 0 (or NaN): the caller stops the replica
         } else if (0.0 / total >= rho) {
             sh->done = 1; sh->idx = 0;                     // searchsorted(left) with rho <= 0
@@ -203,6 +231,7 @@ __device__ __forceinline__ void exact_select_par_impl(KeyFn keys, const double* 
     }
     __syncthreads();
     XP_TRACE(0, 1); XP_TRACE(5, __builtin_amdgcn_s_memtime() - xp_t0);
+    if (fast && sh->done == 3) { __syncthreads(); fast = false; total = 0.0; goto restart; }
     if (sh->done) return;
     const double cstar = sh->cstar;
     const long long two53 = 1LL << 53, two54 = 1LL << 54;
@@ -212,8 +241,35 @@ __device__ __forceinline__ void exact_select_par_impl(KeyFn keys, const double* 
 #pragma unroll
     for (int q = 0; q < KMC_XP_SITES; ++q) {
         const long s = (long)tid * KMC_XP_SITES + q;
-        knext[q] = s < n ? keys(s) : KMC_VACANT;
+        knext[q] = (!STRIPED && s < n) ? keys(s) : KMC_VACANT;
     }
+    // striped reading: piece tid + XP_THREADS * m of the tile = part (piece % 3) of site (piece / 3)
+    constexpr int NP = KMC_XP_SITES * 3;                  // 16-byte pieces per thread and tile
+    uint32_t kstr[STRIPED ? NP : 1];
+    const int tid_part = tid % 3, tid_site = tid / 3;
+    auto stripe_part = [&](int m) -> int { return (tid_part + m * (XP_THREADS % 3)) % 3; };
+    auto stripe_site = [&](int m) -> long { return (long)(m * XP_THREADS + tid) / 3; };
+    auto stripe_keys = [&](long t0) {
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            const long s = t0 / 6 + stripe_site(m);
+            kstr[m] = s < n ? keys(s) : KMC_VACANT;
+        }
+    };
+    (void)tid_site;
+    if (STRIPED) stripe_keys(0);
+    // the striped pieces of the tile at hand, read while the tile before it was summed (vvalid), and then kstr holds the keys
+    // of the tile after it: two tiles of requests are in flight, a tile's sum waits for neither
+    double2 v[STRIPED ? NP : 1];
+    bool vvalid = false;
+    auto stripe_rows = [&](double2* dst) {
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            dst[m] = make_double2(0.0, 0.0);               // vacant, or beyond the lattice: zeros, no request
+            if (kstr[m] <= 0x3FFFFu)
+                dst[m] = *reinterpret_cast<const double2*>(table + (size_t)kstr[m] * 6 + 2 * stripe_part(m));
+        }
+    };
     // The running state (c, pos) is uniform and lives in registers: every thread derives it from the
     // same shared totals.  An event-free tile costs one barrier (wave totals are double-buffered).
     double c = 0.0;
@@ -224,6 +280,50 @@ __device__ __forceinline__ void exact_select_par_impl(KeyFn keys, const double* 
     for (long tile0 = 0; tile0 < n6 && !done; tile0 += XP_TILE) {
         const long tile_end = (tile0 + XP_TILE) < n6 ? (tile0 + XP_TILE) : n6;
         const long e0 = tile0 + (long)tid * NE;
+        if (STRIPED) {
+            if (c > 0.0) {                                 // (pos == tile0 here: every tile is left at its end)
+                if (!vvalid) { stripe_rows(v); stripe_keys(tile0 + XP_TILE); }
+                double2 vn[NP];
+                stripe_rows(vn);                           // the next tile's rows and the keys of the one after it travel
+                stripe_keys(tile0 + 2 * XP_TILE);          // while this one is summed
+                const int ex = ilogb(c);
+                const long long A = (long long)ldexp(c, 52 - ex);
+                const double scale = ldexp(1.0, 52 - ex);
+                long long run = 0;
+                bool flag = false;
+#pragma unroll
+                for (int m = 0; m < 2 * NP; ++m) {
+                    const double pv = (m & 1) ? v[m >> 1].y : v[m >> 1].x;
+                    const double y = pv * scale, z = y + magic, qd = z - magic;
+                    flag = flag | (!(y < magic - 1.0)) | (fabs(qd - y) == 0.5);
+                    run += __double_as_longlong(z) & ((1LL << 52) - 1);
+                }
+                run = (flag || run > two54) ? two54 : run;
+                const long long incl = wave_scan_incl_i64(run);
+                const bool wflag = __builtin_amdgcn_ballot_w64(flag) != 0ull;
+                if (lane == 63) { sh->wave_tot[parity][wv] = incl; sh->wave_flag[parity][wv] = wflag ? 1 : 0; }
+                __syncthreads();
+                long long tot = 0;
+                int anyflag = 0;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) { tot += sh->wave_tot[parity][q]; anyflag |= sh->wave_flag[parity][q]; }
+                parity ^= 1;
+                const double c_end = ldexp((double)(A + tot), ex - 52);      // exact if no event
+#pragma unroll
+                for (int m = 0; m < NP; ++m) v[m] = vn[m];
+                vvalid = true;
+                if (!(anyflag != 0 || A + tot >= two53 || c_end >= cstar)) { c = c_end; pos = tile_end; continue; }
+            } else {
+                stripe_keys(tile0 + XP_TILE);
+                vvalid = false;
+            }
+            // an event in this tile (or the sum still at zero): the owner layout finds it
+#pragma unroll
+            for (int q = 0; q < KMC_XP_SITES; ++q) {
+                const long s = e0 / 6 + q;
+                knext[q] = s < n ? keys(s) : KMC_VACANT;
+            }
+        }
         double p[KMC_XP_SITES * 6];
 #pragma unroll
         for (int q = 0; q < KMC_XP_SITES; ++q) {
@@ -237,7 +337,7 @@ __device__ __forceinline__ void exact_select_par_impl(KeyFn keys, const double* 
 #pragma unroll
         for (int q = 0; q < KMC_XP_SITES; ++q) {          // the next tile's keys travel while this one is summed
             const long s = (e0 + XP_TILE) / 6 + q;
-            knext[q] = s < n ? keys(s) : KMC_VACANT;
+            knext[q] = (!STRIPED && s < n) ? keys(s) : KMC_VACANT;
         }
         const long hi_l = tile_end - e0;
         const int hi_m = hi_l < 0 ? 0 : (hi_l > NE ? NE : (int)hi_l);      // my entries [lo_m, hi_m) are live
@@ -270,7 +370,8 @@ __device__ __forceinline__ void exact_select_par_impl(KeyFn keys, const double* 
                     flag = flag | (sp & live);
                     run += live ? q : 0LL;
                 }
-                run = flag ? two54 : run;                 // saturate: everything behind an event is void
+                run = (flag || run > two54) ? two54 : run;        // saturate: everything behind an event is void (and no
+                                                                  // sum of a tile's quanta can overflow)
             } else {
 #pragma unroll
                 for (int m = 0; m < NE; ++m) flag = flag | ((m >= lo_m) & (m < hi_m) & (p[m] > 0.0));
@@ -344,6 +445,12 @@ __device__ __forceinline__ void exact_select_par_impl(KeyFn keys, const double* 
         }
     }
     __syncthreads();
+    if (fast) {
+        // the short form stands if an entry reached T_hi and the one before it is below T_lo
+        if (tid == 0) sh->done = (sh->idx < n6 && sh->cprev_found < t_lo) ? 1 : 3;
+        __syncthreads();
+        if (sh->done == 3) { __syncthreads(); fast = false; total = 0.0; goto restart; }
+    }
     XP_TRACE(6, __builtin_amdgcn_s_memtime() - xp_t0);
 }
 

@@ -1126,7 +1126,7 @@ int kmc_set_debug(kmc_ctx* c, int force_exact, double margin_scale)
 {
     CTXCHK(c);
     if (!(margin_scale >= 1.0)) return fail(c, KMC_EINVAL, "kmc_set_debug: margin_scale must be >= 1");
-    c->force_exact = force_exact != 0;
+    c->force_exact = force_exact == 2 ? 2 : (force_exact != 0);
     c->margin_scale = margin_scale;
     return KMC_OK;
 }

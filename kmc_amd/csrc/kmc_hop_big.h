@@ -92,7 +92,7 @@ struct HopBigParams {
 struct BigCtrl {                 // wave 0 -> the helper waves
     int seq, stop;               // seq is bumped for every request; stop = leave
     int n_li;                    // Li atoms of the lattice (conserved)
-    double rho;
+    double rho, gam;             // the draw and the tree's gamma of the hop to replay
     uint32_t kscr[6 * 8];        // new keys of the window, [window row][window column]
 };
 
@@ -108,6 +108,18 @@ __device__ __forceinline__ big_params_ptr big_cold_params()
     return kp;
 }
 #define BP (big_cold_params())
+
+// The exact path of this kernel (all four waves).  gamma_hint > 0: the short form of kmc_exact_par.h, which skips the
+// np.sum pass (two thirds of a replay at 1024 x 1024) unless an entry falls inside the band that np.sum decides.
+__device__ __noinline__ void exact_select_big(const uint32_t* __restrict__ keys, const double* __restrict__ table,
+                                              int n, double rho, ExactParShared* sh, double gamma_hint, double delta)
+{
+#ifdef KMC_BIG_XP_OWNER         // scripts/variants_big.py: A/B against the owner layout only
+    exact_select_par_impl<4, 4, false, false>([&](long s) -> uint32_t { return keys[s]; }, table, n, rho, sh, gamma_hint, delta);
+#else
+    exact_select_par_impl<4, 4, false, true>([&](long s) -> uint32_t { return keys[s]; }, table, n, rho, sh, gamma_hint, delta);
+#endif
+}
 
 template <bool COMPACT>
 __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p)
@@ -229,6 +241,10 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     const double mu = p.mu;
     const double xtra = 6.0 * (double)n / 8192.0 + 512.0;
     const bool force_exact = p.force_exact != 0;
+    // kmc_set_debug(force_exact = 1): every hop through the exact path in its long form (np.sum always); 2: every hop
+    // through it, short form allowed -- what a hop that cannot be certified gets
+    const bool xp_short = p.force_exact != 1;
+    const double xp_delta = mu * xtra + 8.0 * 1.1102230246251565e-16;
     const bool presim = p.presim != 0;
 
     // one level of the descent: 8 children at ch[0..7], running base; returns the child picked
@@ -253,7 +269,8 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             while ((sq = *vseq) == seen) __builtin_amdgcn_s_sleep(16);
             seen = sq;
             if (*vstop) break;
-            exact_select_par(keys_g, BP->table, n, *(volatile double*)&ctl->rho, xp);
+            exact_select_big(keys_g, BP->table, n, *(volatile double*)&ctl->rho, xp,
+                             xp_short ? *(volatile double*)&ctl->gam : 0.0, xp_delta);
         }
     }
     double rho_v = 0.5, u_v = 1.0, gam_v = 1.0, pn_v = 1.0;
@@ -586,9 +603,9 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         // reference together
         const double rho = readlane_f64(rho_v, (int)(h & 63));
         __threadfence_block();
-        if (lane == 0) { *(volatile double*)&ctl->rho = rho; *(volatile int*)&ctl->seq = ++seq_sent; }
+        if (lane == 0) { *(volatile double*)&ctl->rho = rho; *(volatile double*)&ctl->gam = gamma; *(volatile int*)&ctl->seq = ++seq_sent; }
         else ++seq_sent;
-        exact_select_par(keys_g, BP->table, n, rho, xp);
+        exact_select_big(keys_g, BP->table, n, rho, xp, xp_short ? gamma : 0.0, xp_delta);
         ++n_exact;
         if (!(xp->gamma > 0.0)) { status = 2; break; }
         if (xp->idx >= 6LL * n) { status = 1; break; }

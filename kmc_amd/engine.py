@@ -290,7 +290,9 @@ class KMCEngine:
         self._chk(self._lib.kmc_set_hop_kernel(self._ctx, int(which) if which is not None else int(bool(generic))))
 
     def set_debug(self, force_exact=False, margin_scale=1.0):
-        self._chk(self._lib.kmc_set_debug(self._ctx, int(bool(force_exact)), float(margin_scale)))
+        """force_exact: every hop through the exact replay of the reference's selection (tests).  2 = the same, but the
+        large-lattice kernel may use the replay's short form (no np.sum pass), as it does for hops it cannot certify."""
+        self._chk(self._lib.kmc_set_debug(self._ctx, 2 if force_exact == 2 else int(bool(force_exact)), float(margin_scale)))
 
     # -- observables ---------------------------------------------------------------
     def diffusion(self, conc, lattice_constant=LATTICE_CONSTANT):
