@@ -398,13 +398,10 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         const int ie = i + di, je = j + dj;                  // unwrapped
         const int iw = wrap1(ie, nx), jw = wrap1(je, ny);
         const int s_dst = iw * ny + jw;
-        if (!presim && lane == 0) {                          // tag move (:521-528)
-            int4 tg = tags_g[s_src];
-            tg.z += ie < 0 ? -1 : (ie >= nx ? 1 : 0);
-            tg.w += je < 0 ? -1 : (je >= ny ? 1 : 0);
-            tags_g[s_dst] = tg;
-            tags_g[s_src] = make_int4(-1, 0, 0, 0);
-        }
+        // tag move (:521-528): the tag is requested here and stored behind the W gathers -- its 16 MB array is read from
+        // HBM, and a store issued here would make the wave wait out that latency on the spot
+        int4 tg = make_int4(0, 0, 0, 0);
+        if (!presim && lane == 0) tg = tags_g[s_src];
         // window geometry (:444-453)
         const int min_di = di < 0 ? di : 0, min_dj = dj < 0 ? dj : 0;
         const int i_lo = wrap1(i - 2 + wm_ext * min_di, nx), j_lo = wrap1(j - 2 + wm_ext * min_dj, ny);
@@ -493,6 +490,12 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         s1[0] = group8_sum(wq[0]);
         s1[1] = group8_sum(wq[1]);
         if (nslots > 2) s1[2] = group8_sum(wq[2]);
+        if (!presim && lane == 0) {
+            tg.z += ie < 0 ? -1 : (ie >= nx ? 1 : 0);
+            tg.w += je < 0 ? -1 : (je >= ny ? 1 : 0);
+            tags_g[s_dst] = tg;
+            tags_g[s_src] = make_int4(-1, 0, 0, 0);
+        }
         KMC_STAMP(5);
         // ---- climb: L2, L3, row (each node = tree of its 8 children, the changed ones replaced) ---
         double s2[3] = {0.0, 0.0, 0.0}, s3[3] = {0.0, 0.0, 0.0};
