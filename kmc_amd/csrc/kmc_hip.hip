@@ -445,16 +445,34 @@ __global__ __launch_bounds__(64) void fill_random_kernel(uint8_t* __restrict__ o
     };
     // smallest T with count(key <= T) >= want
     unsigned long long lo = 0, hi = ~0ull;
-    while (lo < hi) {
-        const unsigned long long mid = lo + ((hi - lo) >> 1);
-        long long c = 0;
-        for (int s = lane; s < n; s += 64) c += site_key64(s) <= mid;
-        c = wave_sum_i64(c);
-        if (c >= want) hi = mid; else lo = mid + 1;
+    long long below = 0;
+    if (n <= 4096) {
+        // the LDS-size lattices of an ensemble: a lane's <= 64 keys are drawn once and stay in registers for the 64
+        // bisection steps (2.1 ms -> 0.1 ms for 4096 x 64 x 64; the same T, the same lattice)
+        unsigned long long kreg[64];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) kreg[q] = q * 64 + lane < n ? site_key64(q * 64 + lane) : 0ull;
+        while (lo < hi) {
+            const unsigned long long mid = lo + ((hi - lo) >> 1);
+            long long c = 0;
+#pragma unroll
+            for (int q = 0; q < 64; ++q) c += (q * 64 + lane < n) & (kreg[q] <= mid);
+            c = wave_sum_i64(c);
+            if (c >= want) hi = mid; else lo = mid + 1;
+        }
+#pragma unroll
+        for (int q = 0; q < 64; ++q) below += (q * 64 + lane < n) & (kreg[q] < lo);
+    } else {
+        while (lo < hi) {
+            const unsigned long long mid = lo + ((hi - lo) >> 1);
+            long long c = 0;
+            for (int s = lane; s < n; s += 64) c += site_key64(s) <= mid;
+            c = wave_sum_i64(c);
+            if (c >= want) hi = mid; else lo = mid + 1;
+        }
+        for (int s = lane; s < n; s += 64) below += site_key64(s) < lo;
     }
     const unsigned long long T = lo;
-    long long below = 0;
-    for (int s = lane; s < n; s += 64) below += site_key64(s) < T;
     below = wave_sum_i64(below);
     int ties_left = want - (int)below;         // ties at T, lowest site index first
     for (int s0 = 0; s0 < n; s0 += 64) {

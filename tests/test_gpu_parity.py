@@ -382,8 +382,9 @@ def test_dense_table_that_does_not_factor(kmc, tables, dense):
 
 
 # ---------------------------------------------------------------- RNG streams / fill
-def test_fill_random_matches_philox(kmc, tables):
-    R, nx, ny = 7, 30, 17
+@pytest.mark.parametrize('nx,ny', [(30, 17), (64, 64), (70, 66)], ids=['30x17', '64x64-keys-in-registers', '70x66-keys-redrawn'])
+def test_fill_random_matches_philox(kmc, tables, nx, ny):
+    R = 7
     conc = np.array([0.0, 0.1, 0.33, 0.5, 0.77, 0.999, 1.0])
     with make_engine(kmc, tables, R, nx, ny) as eng:
         eng.fill_random(conc, 0xDEADBEEF12345)
