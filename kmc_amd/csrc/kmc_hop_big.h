@@ -209,11 +209,13 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     double gamma = readlane_f64(r2pre, 63);
 
     int status = 0;
-    long long n_exact = 0, hops = 0;
+    int n_exact = 0;
     int hist_c = 0;
     long long hist_v = 0;
-    double time_acc = 0.0;
-    double b_last = p.barrier[r * 5 + 0], b_sum = 0.0, b_min = 1e300, b_max = -1e300, b_cnt = 0.0;
+    // flush-only accumulators (clock, barrier statistics: last, sum, min, max, count) live in the 64 spare bytes behind R1,
+    // not in scalar registers that the hop loop would spill (see kmc_hop_q64.h)
+    double* acc_l = R1 + (size_t)g.nr2 * 8;
+    if (tid < 6) acc_l[tid] = tid == 1 ? p.barrier[r * 5 + 0] : (tid == 3 ? 1e300 : (tid == 4 ? -1e300 : 0.0));
     const long long hop0 = p.hops_done[r];
     const long long my_hops = p.n_hops_r ? p.n_hops_r[r] : p.n_hops;
 
@@ -243,8 +245,9 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     const bool force_exact = p.force_exact != 0;
     // kmc_set_debug(force_exact = 1): every hop through the exact path in its long form (np.sum always); 2: every hop
     // through it, short form allowed -- what a hop that cannot be certified gets
-    const bool xp_short = p.force_exact != 1;
-    const double xp_delta = mu * xtra + 8.0 * 1.1102230246251565e-16;
+    // (read where they are used, from the kernel-argument segment: the hop loop has no scalar registers to spare)
+#define BIG_XP_SHORT (BP->force_exact != 1)
+#define BIG_XP_DELTA (BP->mu * (6.0 * (double)BP->g.n / 8192.0 + 512.0) + 8.0 * 1.1102230246251565e-16)
     const bool presim = p.presim != 0;
 
     // one level of the descent: 8 children at ch[0..7], running base; returns the child picked
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             seen = sq;
             if (*vstop) break;
             exact_select_big(keys_g, BP->table, n, *(volatile double*)&ctl->rho, xp,
-                             xp_short ? *(volatile double*)&ctl->gam : 0.0, xp_delta);
+                             BIG_XP_SHORT ? *(volatile double*)&ctl->gam : 0.0, BIG_XP_DELTA);
         }
     }
     double rho_v = 0.5, u_v = 1.0, gam_v = 1.0, pn_v = 1.0;
@@ -426,14 +429,18 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         }
         double c3 = L3[(size_t)si * 8 + grp_c];
         // R1 / R2 nodes above the window rows: up to three distinct R1 parents, group k takes the k-th
-        int rp[3], nrp = 0;
-        for (int a = 0; a < n_i; ++a) {
-            const int pr = wrap1(i_lo + a, nx) >> 3;
-            bool seen = false;
-            for (int k = 0; k < nrp; ++k) seen = seen || rp[k] == pr;
-            if (!seen && nrp < 3) rp[nrp++] = pr;
+        // (in order of first appearance along the window: the parent of row i_lo, that of the last row before the lattice's
+        // edge or of the window's last row, and R1[0] when the window wraps -- fewer than 8 rows span at most two parents on
+        // either side of the edge; a loop over the rows costs ~20 taken branches a hop)
+        int rp[3], nrp = 1;
+        {
+            const int last_row = i_lo + n_i - 1;
+            const bool wraps = last_row >= nx;
+            const int pA = i_lo >> 3, pB = (wraps ? nx - 1 : last_row) >> 3;
+            rp[0] = pA; rp[1] = pA; rp[2] = pA;
+            if (pB != pA) { rp[1] = pB; nrp = 2; }
+            if (wraps && pA != 0 && pB != 0) { if (nrp == 2) rp[2] = 0; else rp[1] = 0; ++nrp; }
         }
-        for (int k = nrp; k < 3; ++k) rp[k] = rp[0];
         const int my_rp = rp[grp_a < 3 ? grp_a : 0];
         const double crow = rowsum[my_rp * 8 + grp_c];                      // the 8 rows under R1[my_rp]
         const double cr1 = R1[(my_rp >> 3) * 8 + grp_c];                    // the 8 R1 under R2[my_rp >> 3]
@@ -454,7 +461,6 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         }
         hist_c += (lane == d);
         if (lane == hl) { gam_v = gamma; pn_v = pnum; idx_v = idx | exact_flag; }
-        ++hops;
         wave_fence();
         KMC_STAMP(3);
         // ---- windowed refresh (:453-465): lane = 8 * (window row) + (window column) ----------
@@ -556,12 +562,15 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         {
             double v = cr1;
             const int first = (my_rp >> 3) * 8 + grp_c;                      // R1 index of this lane's child
-            for (int k = 0; k < nrp; ++k) {
+            // (all three groups, no loop over nrp: a group beyond nrp repeats group 0's parent and so its value)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
                 const double rk = readlane_f64(r1new, k * 8);
                 if (first == rp[k]) v = rk;
             }
             const double r2new = group8_sum(v);                              // group k: new R2[rp[k] >> 3]
-            for (int k = 0; k < nrp; ++k) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
                 const double rk = readlane_f64(r2new, k * 8);
                 if (lane == (rp[k] >> 3)) r2 = rk;
             }
@@ -579,7 +588,8 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             hist_v += hist_c; hist_c = 0;
             if (!presim) {
                 const double dt = lane < done ? (-1.0 / gam_v) * log(u_v) : 0.0;      // :530
-                time_acc += wave_sum(dt);
+                const double ts = wave_sum(dt);
+                if (lane == 0) acc_l[0] += ts;
             }
             const big_params_ptr bp = BP;
             if (bp->sel && lane < done) bp->sel[(size_t)r * bp->n_hops + h0 + lane] = idx_v & 0x3FFFFFFF;
@@ -588,15 +598,17 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             const double bar = has ? -log((pn_v / pd_v) / 1e13) * 0.025 : 0.0;      // :496-498
             const unsigned long long m = __ballot(has);
             if (m) {
-                b_last = readlane_f64(bar, 63 - __builtin_clzll(m));
-                b_sum += wave_sum(bar);
+                const double last = readlane_f64(bar, 63 - __builtin_clzll(m));
+                const double sum = wave_sum(bar);
                 double mn = has ? bar : 1e300, mx = has ? bar : -1e300;
                 for (int off = 32; off > 0; off >>= 1) {
                     mn = fmin(mn, __shfl_xor(mn, off, 64));
                     mx = fmax(mx, __shfl_xor(mx, off, 64));
                 }
-                b_min = fmin(b_min, mn); b_max = fmax(b_max, mx);
-                b_cnt += (double)__popcll(m);
+                if (lane >= 1 && lane < 6) {
+                    const double o = acc_l[lane];
+                    acc_l[lane] = lane == 1 ? last : (lane == 2 ? o + sum : (lane == 3 ? fmin(o, mn) : (lane == 4 ? fmax(o, mx) : o + (double)__popcll(m))));
+                }
             }
         }
     }
@@ -608,7 +620,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         __threadfence_block();
         if (lane == 0) { *(volatile double*)&ctl->rho = rho; *(volatile double*)&ctl->gam = gamma; *(volatile int*)&ctl->seq = ++seq_sent; }
         else ++seq_sent;
-        exact_select_big(keys_g, BP->table, n, rho, xp, xp_short ? gamma : 0.0, xp_delta);
+        exact_select_big(keys_g, BP->table, n, rho, xp, BIG_XP_SHORT ? gamma : 0.0, BIG_XP_DELTA);
         ++n_exact;
         if (!(xp->gamma > 0.0)) { status = 2; break; }
         if (xp->idx >= 6LL * n) { status = 1; break; }
@@ -624,6 +636,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     }
     if (wv == 0) {
         const big_params_ptr bp = BP;
+        const long long hops = h;                           // hops done: h counts completed hops only
         if (status != 0 && hops < my_hops) {
             // a replica that stopped: records of the unfinished chunk, then the trace of what never ran
             const int done = (int)(hops & 63);
@@ -632,7 +645,8 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             if (done > 0) {
                 if (!presim) {
                     const double dt = lane < done ? (-1.0 / gam_v) * log(u_v) : 0.0;
-                    time_acc += wave_sum(dt);
+                    const double ts = wave_sum(dt);
+                    if (lane == 0) acc_l[0] += ts;
                 }
                 if (bp->sel && lane < done) bp->sel[(size_t)r * bp->n_hops + h0 + lane] = idx_v & 0x3FFFFFFF;
                 const bool has = lane < done && (idx_v & 0x3FFFFFFF) != 0;
@@ -640,21 +654,25 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
                 const double bar = has ? -log((pn_v / pd_v) / 1e13) * 0.025 : 0.0;
                 const unsigned long long m = __ballot(has);
                 if (m) {
-                    b_last = readlane_f64(bar, 63 - __builtin_clzll(m));
-                    b_sum += wave_sum(bar);
+                    const double last = readlane_f64(bar, 63 - __builtin_clzll(m));
+                    const double sum = wave_sum(bar);
                     double mn = has ? bar : 1e300, mx = has ? bar : -1e300;
                     for (int off = 32; off > 0; off >>= 1) {
                         mn = fmin(mn, __shfl_xor(mn, off, 64));
                         mx = fmax(mx, __shfl_xor(mx, off, 64));
                     }
-                    b_min = fmin(b_min, mn); b_max = fmax(b_max, mx);
-                    b_cnt += (double)__popcll(m);
+                    if (lane >= 1 && lane < 6) {
+                        const double o = acc_l[lane];
+                        acc_l[lane] = lane == 1 ? last : (lane == 2 ? o + sum : (lane == 3 ? fmin(o, mn) : (lane == 4 ? fmax(o, mx) : o + (double)__popcll(m))));
+                    }
                 }
             }
         }
         if (bp->sel)
             for (long long hh = hops + lane; hh < bp->n_hops; hh += 64) bp->sel[(size_t)r * bp->n_hops + hh] = -1;
         if (lane < 6) bp->hist[r * 6 + lane] += hist_v;
+        wave_fence();
+        const double time_acc = acc_l[0], b_last = acc_l[1], b_sum = acc_l[2], b_min = acc_l[3], b_max = acc_l[4], b_cnt = acc_l[5];
         if (lane == 0) {
             bp->time_total[r] += time_acc;
             bp->step_time[r] = time_acc;
