@@ -729,8 +729,10 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
         c->big_ok = big_geometry(nx, ny, &c->geom);
         c->use_big = c->big_ok;
         if (c->big_ok) {
-            CREATE_CHK(hipFuncSetAttribute((const void*)hop_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, c->geom.lds_bytes));
-            CREATE_CHK(hipFuncSetAttribute((const void*)hop_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, c->geom.lds_bytes));
+            CREATE_CHK(hipFuncSetAttribute((const void*)hop_big_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c->geom.lds_bytes));
+            CREATE_CHK(hipFuncSetAttribute((const void*)hop_big_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c->geom.lds_bytes));
+            CREATE_CHK(hipFuncSetAttribute((const void*)hop_big_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, c->geom.lds_bytes));
+            CREATE_CHK(hipFuncSetAttribute((const void*)hop_big_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, c->geom.lds_bytes));
         }
     }
     CREATE_CHK(hipStreamSynchronize(c->stream));
@@ -1210,10 +1212,15 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         time_begin(c);
         c->run_groups[slot] = 1;
         HIPCHK(c, hipEventRecord(c->run_ev[slot][0][0], c->stream));
-        if (c->have_compact)
-            hop_big_kernel<true><<<c->R, KMC_BIG_THREADS, c->geom.lds_bytes, c->stream>>>(g);
+        const bool three = (c->ny & 7) != 0;                 // L1 blocks a window row can touch
+        if (c->have_compact && three)
+            hop_big_kernel<true, 3><<<c->R, KMC_BIG_THREADS, c->geom.lds_bytes, c->stream>>>(g);
+        else if (c->have_compact)
+            hop_big_kernel<true, 2><<<c->R, KMC_BIG_THREADS, c->geom.lds_bytes, c->stream>>>(g);
+        else if (three)
+            hop_big_kernel<false, 3><<<c->R, KMC_BIG_THREADS, c->geom.lds_bytes, c->stream>>>(g);
         else
-            hop_big_kernel<false><<<c->R, KMC_BIG_THREADS, c->geom.lds_bytes, c->stream>>>(g);
+            hop_big_kernel<false, 2><<<c->R, KMC_BIG_THREADS, c->geom.lds_bytes, c->stream>>>(g);
         HIPCHK(c, hipEventRecord(c->run_ev[slot][0][1], c->stream));
         time_end(c);
         ++c->run_launches;

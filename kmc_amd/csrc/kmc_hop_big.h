@@ -121,7 +121,9 @@ __device__ __noinline__ void exact_select_big(const uint32_t* __restrict__ keys,
 #endif
 }
 
-template <bool COMPACT>
+// NSLOTS = L1 blocks a window row can touch: 2 when ny is a multiple of 8 (the third slot's code is then gone, with the
+// uniform branches round it -- a taken branch costs this kernel's lone wave ~27 cycles), else 3
+template <bool COMPACT, int NSLOTS>
 __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     const int wm_ext = p.window_mode == 1 ? 0 : 1;
     const int wm_ni0 = p.window_mode == 0 ? 4 : 5;
     const int wm_nj0 = p.window_mode == 0 ? 4 : (p.window_mode == 1 ? 6 : 5);
-    const int nslots = (ny & 7) ? 3 : 2;                // L1 blocks a window row can touch
+    constexpr int nslots = NSLOTS;                      // L1 blocks a window row can touch: (ny & 7) ? 3 : 2
     const double mu = p.mu;
     const double xtra = 6.0 * (double)n / 8192.0 + 512.0;
     const bool force_exact = p.force_exact != 0;
