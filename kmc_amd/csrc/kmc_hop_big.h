@@ -326,7 +326,11 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             // 64 rows of group g2 at once (LDS), then the row's L2 nodes at once (<= 64, one global read)
             {
                 const int ri = g2 * 64 + lane;
-                const double sc = wave_scan_incl(ri < g.nr1 * 8 ? rowsum[ri] : 0.0);
+                // (loads that sat under a lane condition are read at a clamped, valid address and selected afterwards: a
+                // guarded load costs an exec save / restore and a skip branch the compiler keeps round memory operations)
+                const int rmax = g.nr1 * 8 - 1;
+                const double rs_v = rowsum[ri < rmax ? ri : rmax];
+                const double sc = wave_scan_incl(ri <= rmax ? rs_v : 0.0);
                 const double bp = base + sc;
                 const double bpe = base + dpp_f64<0x138, 0xF>(sc);
                 const unsigned long long mb = ballot64(bp >= t);
@@ -338,7 +342,8 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             }
             int b2;
             {
-                const double sc = wave_scan_incl(lane < g.S2 ? L2[(size_t)i * g.S2 + lane] : 0.0);
+                const double l2_v = L2[(size_t)i * g.S2 + (lane < g.S2 ? lane : g.S2 - 1)];
+                const double sc = wave_scan_incl(lane < g.S2 ? l2_v : 0.0);
                 const double bp = base + sc;
                 const double bpe = base + dpp_f64<0x138, 0xF>(sc);
                 const unsigned long long mb = ballot64(bp >= t);
@@ -352,7 +357,8 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             KMC_STAMP(1);
             // ---- entry: 8 sites x 6 directions on 48 lanes ---------------------------------
             const int ej = b1 * 8 + ent_site;
-            const uint32_t ek = ej < ny ? wkey(keys_g[(size_t)i * ny + ej]) : KMC_BIG_VAC;
+            const uint32_t ek_v = wkey(keys_g[(size_t)i * ny + (ej < ny ? ej : ny - 1)]);
+            const uint32_t ek = ej < ny ? ek_v : KMC_BIG_VAC;
             double rate;
             if (COMPACT) {
                 uint32_t ci = __builtin_amdgcn_ubfe(ek, cf_st[0], cf_ln[0]);
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         // tag move (:521-528): the tag is requested here and stored behind the W gathers -- its 16 MB array is read from
         // HBM, and a store issued here would make the wave wait out that latency on the spot
         int4 tg = make_int4(0, 0, 0, 0);
-        if (!presim && lane == 0) tg = tags_g[s_src];
+        if (!presim) tg = tags_g[s_src];                     // every lane, one address: one request
         // window geometry (:444-453)
         const int min_di = di < 0 ? di : 0, min_dj = dj < 0 ? dj : 0;
         const int i_lo = wrap1(i - 2 + wm_ext * min_di, nx), j_lo = wrap1(j - 2 + wm_ext * min_dj, ny);
@@ -425,7 +431,10 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int cj = bs[q] * 8 + grp_c;
-            kold[q] = (q < nslots && cj < ny) ? keys_g[(size_t)si * ny + cj] : KMC_VACANT;
+            if (q < nslots) {
+                const uint32_t kv = keys_g[(size_t)si * ny + (cj < ny ? cj : ny - 1)];
+                kold[q] = cj < ny ? kv : KMC_VACANT;
+            } else kold[q] = KMC_VACANT;
             c1[q] = q < nslots ? L1[(size_t)si * g.S1 + (bs[q] >> 3) * 8 + grp_c] : 0.0;      // siblings under its L2 parent
             c2[q] = q < nslots ? L2[(size_t)si * g.S2 + (bs[q] >> 6) * 8 + grp_c] : 0.0;      // siblings under its L3 parent
         }
@@ -487,12 +496,14 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         double s1[3] = {0.0, 0.0, 0.0}, wq[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < 3; ++q) {                                         // all gathers in flight together
-            if (q < nslots && act) {
+            if (q < nslots) {
                 const int cj = bs[q] * 8 + grp_c;
                 int wc = cj - j_lo;
                 if (wc < 0) wc += ny;
-                const uint32_t k = (cj < ny && wc < n_j) ? ctl->kscr[grp_a * 8 + wc] : kold[q];
-                wq[q] = wsum[wkey(k)];
+                const uint32_t kw = ctl->kscr[(act ? grp_a : 0) * 8 + (wc & 7)];
+                const uint32_t k = (cj < ny && wc < n_j) ? kw : kold[q];
+                const double wv_ = wsum[wkey(k)];            // a lane of an idle group reads row i_lo's keys: valid, unused
+                wq[q] = act ? wv_ : 0.0;
             }
         }
         s1[0] = group8_sum(wq[0]);
