@@ -151,6 +151,16 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     const unsigned char* __restrict__ table_b = reinterpret_cast<const unsigned char*>(p.table);
     const unsigned char* __restrict__ tc_b = reinterpret_cast<const unsigned char*>(p.tcompact);
     auto wkey = [](uint32_t k) -> uint32_t { return k > 0x3FFFFu ? KMC_BIG_VAC : k; };   // KMC_VACANT -> zero row
+    // Hop-loop accesses: ONE 32-bit element index off a base pointer (scalar base + 32-bit vector offset, the cheapest global
+    // address form) instead of 64-bit per-lane pointer arithmetic; a replica's arrays are far below 4 GB.  hidx = index into
+    // the replica's slab of sums (L1, L2, L3 at g.offL1 / offL2 / offL3).
+    const unsigned char* hier_b = reinterpret_cast<const unsigned char*>(hier);
+    const unsigned char* keys_b = reinterpret_cast<const unsigned char*>(keys_g);
+    const uint32_t oL1 = (uint32_t)g.offL1, oL2 = (uint32_t)g.offL2, oL3 = (uint32_t)g.offL3;
+    auto ld_h = [&](uint32_t hidx) -> double { asm("" : "+v"(hidx)); return *reinterpret_cast<const double*>(hier_b + (hidx << 3)); };
+    const unsigned char* wsum_b = reinterpret_cast<const unsigned char*>(wsum);
+    auto ld_w = [&](uint32_t k) -> double { asm("" : "+v"(k)); return *reinterpret_cast<const double*>(wsum_b + (k << 3)); };
+    auto ld_k = [&](uint32_t s) -> uint32_t { asm("" : "+v"(s)); return *reinterpret_cast<const uint32_t*>(keys_b + (s << 2)); };
 
     // bit (row rr, column cc) with rr in [-2, nx + 1], cc in [-2, ny + 1]
     auto bm_word = [&](int rr, int cc) -> int { return (cc + 2) * cw + ((rr + 2) >> 5); };
@@ -253,8 +263,8 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     const bool presim = p.presim != 0;
 
     // one level of the descent: 8 children at ch[0..7], running base; returns the child picked
-    auto descend = [&](const double* ch, double t, double& base, bool& ok) -> int {
-        const double sc = scan8_incl(ch[grp_c]);
+    auto descend = [&](uint32_t ch, double t, double& base, bool& ok) -> int {     // ch = slab index of child 0
+        const double sc = scan8_incl(ld_h(ch + (uint32_t)grp_c));
         const double bp = base + sc;
         const double bpe = base + dpp_f64<0x111, 0xF>(sc);
         const unsigned long long mb = ballot64(bp >= t) & 0xFFull;
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             }
             int b2;
             {
-                const double l2_v = L2[(size_t)i * g.S2 + (lane < g.S2 ? lane : g.S2 - 1)];
+                const double l2_v = ld_h(oL2 + (uint32_t)i * (uint32_t)g.S2 + (uint32_t)(lane < g.S2 ? lane : g.S2 - 1));
                 const double sc = wave_scan_incl(lane < g.S2 ? l2_v : 0.0);
                 const double bp = base + sc;
                 const double bpe = base + dpp_f64<0x138, 0xF>(sc);
@@ -352,21 +362,25 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
                 base = readlane_f64(bpe, b2);
                 if (b2 >= (g.S1 >> 3)) { ok = false; b2 = 0; }
             }
-            int b1 = b2 * 8 + descend(L1 + (size_t)i * g.S1 + b2 * 8, t, base, ok);
+            int b1 = b2 * 8 + descend(oL1 + (uint32_t)i * (uint32_t)g.S1 + (uint32_t)b2 * 8u, t, base, ok);
             if (b1 >= g.nb1) { ok = false; b1 = 0; }
             KMC_STAMP(1);
             // ---- entry: 8 sites x 6 directions on 48 lanes ---------------------------------
             const int ej = b1 * 8 + ent_site;
-            const uint32_t ek_v = wkey(keys_g[(size_t)i * ny + (ej < ny ? ej : ny - 1)]);
+            const uint32_t ek_v = wkey(ld_k((uint32_t)i * (uint32_t)ny + (uint32_t)(ej < ny ? ej : ny - 1)));
             const uint32_t ek = ej < ny ? ek_v : KMC_BIG_VAC;
             double rate;
             if (COMPACT) {
                 uint32_t ci = __builtin_amdgcn_ubfe(ek, cf_st[0], cf_ln[0]);
 #pragma unroll
                 for (int f = 1; f < 5; ++f) ci |= __builtin_amdgcn_ubfe(ek, cf_st[f], cf_ln[f]) << cf_sh[f];
-                rate = *reinterpret_cast<const double*>(tc_b + ((ci << 3) + ent_off));
+                uint32_t ro = (ci << 3) + ent_off;
+                asm("" : "+v"(ro));
+                rate = *reinterpret_cast<const double*>(tc_b + ro);
             } else {
-                rate = *reinterpret_cast<const double*>(table_b + (ek * 48u + ent_off));
+                uint32_t ro = ek * 48u + ent_off;
+                asm("" : "+v"(ro));
+                rate = *reinterpret_cast<const double*>(table_b + ro);
             }
             const double esc = wave_scan_incl(rate);
             const double ap = base + esc;
@@ -412,7 +426,11 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         // tag move (:521-528): the tag is requested here and stored behind the W gathers -- its 16 MB array is read from
         // HBM, and a store issued here would make the wave wait out that latency on the spot
         int4 tg = make_int4(0, 0, 0, 0);
-        if (!presim) tg = tags_g[s_src];                     // every lane, one address: one request
+        if (!presim) {                                       // every lane, one address: one request
+            uint32_t to = (uint32_t)s_src << 4;
+            asm("" : "+v"(to));
+            tg = *reinterpret_cast<const int4*>(reinterpret_cast<const unsigned char*>(tags_g) + to);
+        }
         // window geometry (:444-453)
         const int min_di = di < 0 ? di : 0, min_dj = dj < 0 ? dj : 0;
         const int i_lo = wrap1(i - 2 + wm_ext * min_di, nx), j_lo = wrap1(j - 2 + wm_ext * min_dj, ny);
@@ -428,17 +446,21 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         // children of every tree node the window will change
         uint32_t kold[3];
         double c1[3], c2[3];
+        // this lane's row in each array (24-bit multiplies: rows and strides are far below 2^24)
+        const uint32_t si_ny = __umul24((uint32_t)si, (uint32_t)ny);
+        const uint32_t si_L1 = oL1 + __umul24((uint32_t)si, (uint32_t)g.S1), si_L2 = oL2 + __umul24((uint32_t)si, (uint32_t)g.S2),
+                       si_L3 = oL3 + (uint32_t)si * 8u;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int cj = bs[q] * 8 + grp_c;
             if (q < nslots) {
-                const uint32_t kv = keys_g[(size_t)si * ny + (cj < ny ? cj : ny - 1)];
+                const uint32_t kv = ld_k(si_ny + (uint32_t)(cj < ny ? cj : ny - 1));
                 kold[q] = cj < ny ? kv : KMC_VACANT;
             } else kold[q] = KMC_VACANT;
-            c1[q] = q < nslots ? L1[(size_t)si * g.S1 + (bs[q] >> 3) * 8 + grp_c] : 0.0;      // siblings under its L2 parent
-            c2[q] = q < nslots ? L2[(size_t)si * g.S2 + (bs[q] >> 6) * 8 + grp_c] : 0.0;      // siblings under its L3 parent
+            c1[q] = q < nslots ? ld_h(si_L1 + (uint32_t)((bs[q] >> 3) * 8 + grp_c)) : 0.0;      // siblings under its L2 parent
+            c2[q] = q < nslots ? ld_h(si_L2 + (uint32_t)((bs[q] >> 6) * 8 + grp_c)) : 0.0;      // siblings under its L3 parent
         }
-        double c3 = L3[(size_t)si * 8 + grp_c];
+        double c3 = ld_h(si_L3 + (uint32_t)grp_c);
         // R1 / R2 nodes above the window rows: up to three distinct R1 parents, group k takes the k-th
         // (in order of first appearance along the window: the parent of row i_lo, that of the last row before the lattice's
         // edge or of the window's last row, and R1[0] when the window wraps -- fewer than 8 rows span at most two parents on
@@ -487,7 +509,11 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             uint32_t knew = ((w2 & 7u) << 15) | ((w1 & 15u) << 11) | (((w0 >> 3) & 3u) << 9) | ((w0 & 3u) << 7) |
                             (((m1 >> 1) & 15u) << 3) | ((m2 >> 2) & 7u);
             knew = (w0 & 4u) ? knew : KMC_VACANT;
-            keys_g[(size_t)si * ny + sj] = knew;
+            {
+                uint32_t ks = si_ny + (uint32_t)sj;
+                asm("" : "+v"(ks));
+                *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(keys_g) + (ks << 2)) = knew;
+            }
             ctl->kscr[grp_a * 8 + grp_c] = knew;
         }
         wave_fence();
@@ -502,7 +528,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
                 if (wc < 0) wc += ny;
                 const uint32_t kw = ctl->kscr[(act ? grp_a : 0) * 8 + (wc & 7)];
                 const uint32_t k = (cj < ny && wc < n_j) ? kw : kold[q];
-                const double wv_ = wsum[wkey(k)];            // a lane of an idle group reads row i_lo's keys: valid, unused
+                const double wv_ = ld_w(wkey(k));            // a lane of an idle group reads row i_lo's keys: valid, unused
                 wq[q] = act ? wv_ : 0.0;
             }
         }
@@ -546,10 +572,15 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             const double v1 = q == 0 ? s1[0] : (q == 1 ? s1[1] : s1[2]);
             const double v2 = q == 0 ? s2[0] : (q == 1 ? s2[1] : s2[2]);
             const double v3 = q == 0 ? s3[0] : s3[1];
-            double* ptr = grp_c < 3 ? L1 + (size_t)si * g.S1 + bq
-                        : (grp_c < 6 ? L2 + (size_t)si * g.S2 + (bq >> 3) : L3 + (size_t)si * 8 + (bq >> 6));
-            if (act && q < nslots) *ptr = grp_c < 3 ? v1 : (grp_c < 6 ? v2 : v3);
-            if (nslots > 2 && act && grp_c == 0) L3[(size_t)si * 8 + (bs[2] >> 6)] = s3[2];
+            uint32_t hs = grp_c < 3 ? si_L1 + (uint32_t)bq : (grp_c < 6 ? si_L2 + (uint32_t)(bq >> 3) : si_L3 + (uint32_t)(bq >> 6));
+            asm("" : "+v"(hs));
+            unsigned char* hier_w = reinterpret_cast<unsigned char*>(hier);
+            if (act && q < nslots) *reinterpret_cast<double*>(hier_w + (hs << 3)) = grp_c < 3 ? v1 : (grp_c < 6 ? v2 : v3);
+            if (nslots > 2 && act && grp_c == 0) {
+                uint32_t h3 = si_L3 + (uint32_t)(bs[2] >> 6);
+                asm("" : "+v"(h3));
+                *reinterpret_cast<double*>(hier_w + (h3 << 3)) = s3[2];
+            }
         }
         {
 #pragma unroll
