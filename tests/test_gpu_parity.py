@@ -258,6 +258,11 @@ def _oracle_run(occ, dense, mode, draws_pre, draws_sim, conc):
     (9, 61, 3, 200, 800, 'obj_ref', 1.0),
     (40, 20, 3, 300, 900, 'full', 1.0),
     (35, 62, 3, 400, 1200, 'hex_ref', 3e7),
+    (8, 64, 3, 200, 800, 'full', 1.0),            # a 7-row window on 8 rows
+    (64, 8, 3, 200, 800, 'obj_ref', 1.0),         # a 6-column window on 8 columns
+    (16, 16, 3, 150, 600, 'full', 1.0),
+    (48, 33, 3, 400, 1200, 'hex_ref', 1.0),
+    (33, 48, 3, 400, 1200, 'obj_ref', 1.0),
     # inflated margin: a few percent of the hops take the exact path, mixed in
     (30, 30, 4, 600, 1500, 'hex_ref', 3e7),
     (64, 64, 2, 100, 300, 'hex_ref', 1.5e6),
