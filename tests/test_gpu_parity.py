@@ -541,6 +541,31 @@ def test_global_memory_kernel_vs_oracle(kmc, tables, dense, cfg, kernel):
         assert 0 < st['n_exact'].sum() < 0.5 * R * (hp + hs)
 
 
+@pytest.mark.parametrize('nx,ny,table,hops', [(130, 70, 'normcons', 6000), (200, 136, 'master', 3000)],
+                         ids=['130x70-normcons', '200x136-master'])
+def test_exact_short_form_equals_long_form(kmc, tables, nx, ny, table, hops):
+    """The exact replay's short form (no np.sum pass: kmc_exact_par.h, gamma_hint) against its long form, every hop forced
+    through either, over thousands of hops and three concentrations -- far more replays than the oracle can follow at this
+    size.  One differing index would send the trajectories apart.  The master fold's rates span 20 decades: binade
+    crossings and events all the way."""
+    R = 3
+    out = []
+    for force in (1, 2, 0):                      # 0: the certified selection, which must agree with the replays as well
+        with make_engine(kmc, tables, R, nx, ny, 'hex_ref', table) as eng:
+            assert not eng.uses_lds_path
+            eng.set_debug(force_exact=force)
+            eng.fill_random([0.25, 0.5, 0.8], 21)
+            eng.rates_full()
+            eng.init_displacements()
+            idx = eng.run(hops, presim=False, seed=0xABCDEF, want_trace=True)
+            st = eng.status()
+            assert not st['status'].any() and (force == 0 or (st['n_exact'] == hops).all())
+            out.append((idx, eng.get_lattice(), eng.get_keys(), eng.get_displacements(), eng.scalars()['time']))
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert np.array_equal(a, b)
+
+
 def test_large_lattice_1024(kmc, tables, dense):
     """BASELINE config 4: one 1024 x 1024 lattice.  Hop-for-hop against the C oracle
     on a short run, then size-independent invariants on a longer Philox run."""
