@@ -354,6 +354,36 @@ def test_lds64_kernel_equals_generic_kernel(kmc, tables, mode):
     assert lds64[11].sum() > 0 and q64[11].sum() > 0 and not q64[7].any()
 
 
+@pytest.mark.parametrize('nx,ny,mode', [(30, 30, 'hex_ref'), (37, 53, 'obj_ref'), (61, 35, 'full'), (12, 9, 'hex_ref')],
+                         ids=lambda v: str(v))
+def test_any_size_q_kernel_equals_block_sum_kernel(kmc, tables, nx, ny, mode):
+    """hop_q64_kernel<., ANY> (the 16-per-CU layout at any size, the default) against hop_lds_kernel (block sums in LDS, which
+    the oracle tests pin) over 6 x 10^5 hops, all concentrations, certified and with an inflated margin: selections,
+    lattices, keys, displacements and histograms identical; clocks and gamma agree to rounding (another fixed summation order)."""
+    R, hp, hs, seed = 45, 1000 + 37, 12000, 0xFEED
+    conc = np.repeat(np.linspace(0.1, 0.9, 9), 5)
+    out = []
+    for which in (4, 1):
+        with make_engine(kmc, tables, R, nx, ny, mode) as eng:
+            eng.set_hop_kernel(which=which)
+            eng.fill_random(conc, 5)
+            eng.rates_full()
+            i1 = eng.run(hp, presim=True, seed=seed, want_trace=True)
+            eng.init_displacements()
+            i2 = eng.run(hs, presim=False, seed=seed, want_trace=True)
+            eng.set_debug(force_exact=False, margin_scale=5e6)
+            i3 = eng.run(300, presim=False, seed=seed, want_trace=True)
+            sc, st = eng.scalars(), eng.status()
+            out.append((i1, i2, i3, eng.get_lattice(), eng.get_keys(), eng.get_displacements(), sc['hist'], st['status'],
+                        sc['time'], sc['step_time'], sc['gamma'], st['n_exact']))
+    q, blk = out
+    for k in range(8):
+        assert np.array_equal(q[k], blk[k])
+    for k in (8, 9, 10):
+        np.testing.assert_allclose(q[k], blk[k], rtol=1e-13)
+    assert q[11].sum() > 0 and not q[7].any()
+
+
 def test_dense_table_that_does_not_factor(kmc, tables, dense):
     """A user table (kmc_set_hex_table) need not depend on 13 key bits per direction only: the
     engine must notice and keep the dense gather; trajectories still match the oracle."""
