@@ -358,7 +358,9 @@ def shard(total, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=400)         # 1.5 s of timed region at 3.8 ms per step
+    # default: 2000 steps = 7 s of timed region at 3.6 ms per step, long enough for a 5-second utilisation sampler to see the
+    # GPU busy (config 4's step is 55 ms: 200)
+    ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--replicas', type=int, default=ENSEMBLE, help='replicas per GPU (weak) / in total (strong)')
@@ -369,6 +371,8 @@ def main():
                     help='BASELINE.json config to run: 5 (default) is the metric\'s workload; 1-4 are its parity-test cases')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 200 if args.config == 4 else 2000
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))

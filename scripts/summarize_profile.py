@@ -13,7 +13,7 @@ src = os.path.join(ROOT, 'gpurun_out', 'prof_' + tag)
 dst = os.path.join(ROOT, 'profiles')
 stats = glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv'))[0]
 shutil.copy(stats, os.path.join(dst, tag + '_kernel_stats.csv'))
-out = {'tag': tag, 'kernel': kern, 'command': 'kernel trace: python3 bench.py --no-cpu-baseline (default 400 + 20 steps); '
+out = {'tag': tag, 'kernel': kern, 'command': 'kernel trace: python3 bench.py --steps 400 --warmup 20 --no-cpu-baseline; '
        'counters: python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline', 'counters': {}}
 for row in csv.DictReader(open(stats)):
     if kern in row['Name']:
