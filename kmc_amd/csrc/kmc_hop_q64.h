@@ -491,7 +491,9 @@ void hop_q64_kernel(HopParams p)
             const int i_lo = ii - 2 + (wm_ext & min_di), n_i = wm_ni0 + (wm_ext & di & 1);     // scalar integer ops only
             const int j_lo = j - 2 + (wm_ext & min_dj), n_j = wm_nj0 + (wm_ext & dj & 1);
             int si;                                              // this group's lattice row
-            if (ANY) { si = i_lo + grp_a; si = si < 0 ? si + nx : (si >= nx ? si - nx : si); }
+            // (ANY: the window's first row and column are wrapped once, as scalars; a lane's offset then needs one compare)
+            const int i_lo0 = ANY ? (i_lo < 0 ? i_lo + nx : i_lo) : 0, j_lo0 = ANY ? (j_lo < 0 ? j_lo + ny : j_lo) : 0;
+            if (ANY) { si = i_lo0 + grp_a; si = si >= nx ? si - nx : si; }
             else si = (i_lo + grp_a) & 63;
             const bool act = grp_a < n_i;
             int qa, qb, qc = 0;
@@ -521,7 +523,7 @@ void hop_q64_kernel(HopParams p)
             // ---- windowed refresh (:453-465): this lane's window column is the one = c (mod 8)
             const int wcol = ANY ? grp_c : (grp_c - j_lo) & 7;
             int sj;
-            if (ANY) { sj = j_lo + wcol; sj = sj < 0 ? sj + ny : (sj >= ny ? sj - ny : sj); }
+            if (ANY) { sj = j_lo0 + wcol; sj = sj >= ny ? sj - ny : sj; }
             else sj = (j_lo + wcol) & 63;
             const bool inw = act & (wcol < n_j);
             uint32_t knew;
@@ -619,7 +621,7 @@ void hop_q64_kernel(HopParams p)
             {
                 // from group a to the lane that owns row i_lo + a
                 int rel;
-                if (ANY) { rel = lane - i_lo; rel = rel < 0 ? rel + nx : (rel >= nx ? rel - nx : rel); }
+                if (ANY) { rel = lane - i_lo0; rel = rel < 0 ? rel + nx : rel; }      // lanes >= nx are masked below
                 else rel = (lane - i_lo) & 63;
                 const int src = (rel & 7) << 5;                  // byte address of lane 8 * rel
                 const bool take = ANY ? (rel < n_i) & (lane < nx) : rel < n_i;
