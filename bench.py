@@ -278,6 +278,13 @@ def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red
                n_exact=int(st['n_exact'].sum()), stopped=int((st['status'] != 0).sum()),
                stats=ensemble.finalize(acc, [CONC])[0], fold_ms=fold_ms, rates_ms=rates_ms,
                hops_per_step=hops_per_step, base512=base512)
+    # For information (not `value`): the same kernel when a run is ONE launch of many KMC steps, as ensemble.run_ensemble
+    # and the sweep driver make them -- no prologue / write-back / tail per 2048 hops.  After everything that is reported.
+    long_steps = 32
+    eng.run(hops_per_step * long_steps, presim=False, seed=SEED)
+    eng.sync()
+    out['long_launch'] = dict(kmc_steps_per_launch=long_steps, kernel_ms=eng.last_kernel_ms(),
+                              hops_per_s_this_rank=R * hops_per_step * long_steps / (eng.last_kernel_ms() * 1e-3))
     if rccl is not None:
         eng.comm_destroy(rccl[1])
     eng.close()
@@ -513,6 +520,7 @@ def main():
         'exact_path_hops': m['n_exact'], 'stopped_replicas': m['stopped'],
         'd_star_mean': m['stats']['d_star'], 'd_star_std': m['stats']['error_star'], 'd_j_mean': m['stats']['d_j'],
         'stage_ms': {'table_fold': m['fold_ms'], 'rates_full': m['rates_ms']},
+        'long_launch_rank0': m['long_launch'],
     }
     if other is not None:
         out['other_scaling'] = other
