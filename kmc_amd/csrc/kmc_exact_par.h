@@ -454,11 +454,12 @@ restart:
     XP_TRACE(6, __builtin_amdgcn_s_memtime() - xp_t0);
 }
 
-// the 256-thread instance of the large-lattice kernels; keys in global memory, KMC_VACANT = vacant
+// the 256-thread instance of hop_global_kernel (striped tiles, short form on request); keys in global memory,
+// KMC_VACANT = vacant
 __device__ __noinline__ void exact_select_par(const uint32_t* __restrict__ keys, const double* __restrict__ table,
-                                              int n, double rho, ExactParShared* sh)
+                                              int n, double rho, ExactParShared* sh, double gamma_hint, double delta)
 {
-    exact_select_par_impl<4, 4, false>([&](long s) -> uint32_t { return keys[s]; }, table, n, rho, sh);
+    exact_select_par_impl<4, 4, false, true>([&](long s) -> uint32_t { return keys[s]; }, table, n, rho, sh, gamma_hint, delta);
 }
 
 }  // namespace kmc

@@ -1238,7 +1238,7 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         memset(&g, 0, sizeof(g));
         g.nx = c->nx; g.ny = c->ny; g.n = c->n; g.window_mode = c->window_mode;
         g.n_hops = n_hops; g.n_hops_r = dcounts; g.presim = presim != 0; g.force_exact = c->force_exact;
-        g.mfac = mfac;
+        g.mfac = mfac; g.mu = ldexp(1.0, -53) * 1.001 * c->margin_scale;
         g.table = c->table; g.wsum = c->wsum; g.occ = c->occ; g.keys = c->keys; g.w = c->w_g; g.tags = c->tags;
         g.draws = draws ? c->draws : nullptr; g.sel = sel_out ? c->sel : nullptr;
         g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32); g.rid_base = c->rid_base;

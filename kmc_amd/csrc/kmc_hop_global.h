@@ -27,7 +27,8 @@ struct HopGlobalParams {
     long long n_hops;
     const long long* n_hops_r;
     int presim, force_exact;
-    double mfac;
+    double mfac;                 // the flat margin factor of the LDS kernels (unused here)
+    double mu;                   // 2^-53 * 1.001 * margin_scale: unit of the position-dependent margin (kmc_hop_big.h)
     const double* table;
     const double* wsum;
     uint8_t* occ;
@@ -149,7 +150,11 @@ __global__ __launch_bounds__(KMC_GB_THREADS) void hop_global_kernel(HopGlobalPar
         }
         const double incl = block_scan_incl(loc, sh, &gamma);
         const double t = rho * gamma;
-        const double M = gamma * p.mfac;
+        // Margin of the chosen entry, as in kmc_hop_big.h: the reference's sequential sum has rounded at most 6 (site + 1)
+        // times when it reaches the entry, each time by <= u relative to a partial sum <= hi; this kernel's own sums (< 70
+        // roundings), np.sum's 6n / 8192 + 30 and the quotient's are in xtra.  A third of the flat gamma * 6n * u on average:
+        // at 2048 x 2048, 1.4 % of the hops were replayed with the flat margin.
+        const double xtra = 6.0 * (double)n / 8192.0 + 512.0;
         bool ok = (gamma > 0.0) && !p.force_exact;
         int first = block_first(ok && incl >= t, sh);
         if (first == KMC_GB_THREADS) ok = false;
@@ -205,7 +210,10 @@ __global__ __launch_bounds__(KMC_GB_THREADS) void hop_global_kernel(HopGlobalPar
                             if (cn >= t) { found = 1; sh->d = dd; sh->lo = cc; sh->hi = cn; sh->pnorm = rate / gamma; break; }
                             cc = cn;
                         }
-                        if (found && !((sh->hi - t >= M) && (t - sh->lo >= M))) found = 0;
+                        if (found) {
+                            const double M = sh->hi * (p.mu * (6.0 * (double)(i * ny + j + 1) + xtra));
+                            if (!((sh->hi - t >= M) && (t - sh->lo >= M))) found = 0;
+                        }
                     }
                 }
                 sh->ok = found;
@@ -217,7 +225,9 @@ __global__ __launch_bounds__(KMC_GB_THREADS) void hop_global_kernel(HopGlobalPar
         double pnorm;
         if (!ok) {
             __syncthreads();
-            exact_select_par(keys, p.table, n, rho, &sh->xp);
+            // (force_exact = 1: always the replay's long form; otherwise its short form where np.sum cannot matter)
+            exact_select_par(keys, p.table, n, rho, &sh->xp, p.force_exact == 1 ? 0.0 : gamma,
+                             p.mu * xtra + 8.0 * 1.1102230246251565e-16);
             ++n_exact;
             const long long idx = sh->xp.idx;
             const double g = sh->xp.gamma;

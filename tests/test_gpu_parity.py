@@ -571,9 +571,10 @@ def test_global_memory_kernel_vs_oracle(kmc, tables, dense, cfg, kernel):
         assert 0 < st['n_exact'].sum() < 0.5 * R * (hp + hs)
 
 
-@pytest.mark.parametrize('nx,ny,table,hops', [(130, 70, 'normcons', 6000), (200, 136, 'master', 3000)],
-                         ids=['130x70-normcons', '200x136-master'])
-def test_exact_short_form_equals_long_form(kmc, tables, nx, ny, table, hops):
+@pytest.mark.parametrize('nx,ny,table,hops,generic', [(130, 70, 'normcons', 6000, False), (200, 136, 'master', 3000, False),
+                                                      (130, 70, 'normcons', 3000, True), (90, 150, 'master', 2000, True)],
+                         ids=['130x70-normcons', '200x136-master', '130x70-normcons-global', '90x150-master-global'])
+def test_exact_short_form_equals_long_form(kmc, tables, nx, ny, table, hops, generic):
     """The exact replay's short form (no np.sum pass: kmc_exact_par.h, gamma_hint) against its long form, every hop forced
     through either, over thousands of hops and three concentrations -- far more replays than the oracle can follow at this
     size.  One differing index would send the trajectories apart.  The master fold's rates span 20 decades: binade
@@ -583,6 +584,7 @@ def test_exact_short_form_equals_long_form(kmc, tables, nx, ny, table, hops):
     for force in (1, 2, 0):                      # 0: the certified selection, which must agree with the replays as well
         with make_engine(kmc, tables, R, nx, ny, 'hex_ref', table) as eng:
             assert not eng.uses_lds_path
+            eng.set_hop_kernel(generic=generic)          # hop_big_kernel, or hop_global_kernel (same replay, its own margin)
             eng.set_debug(force_exact=force)
             eng.fill_random([0.25, 0.5, 0.8], 21)
             eng.rates_full()
