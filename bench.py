@@ -280,11 +280,14 @@ def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red
                hops_per_step=hops_per_step, base512=base512)
     # For information (not `value`): the same kernel when a run is ONE launch of many KMC steps, as ensemble.run_ensemble
     # and the sweep driver make them -- no prologue / write-back / tail per 2048 hops.  After everything that is reported.
-    long_steps = 32
-    eng.run(hops_per_step * long_steps, presim=False, seed=SEED)
-    eng.sync()
-    out['long_launch'] = dict(kmc_steps_per_launch=long_steps, kernel_ms=eng.last_kernel_ms(),
-                              hops_per_s_this_rank=R * hops_per_step * long_steps / (eng.last_kernel_ms() * 1e-3))
+    # (--no-long-launch: the profile passes average their counters over the launches of ONE size)
+    out['long_launch'] = None
+    if not args.no_long_launch:
+        long_steps = 32
+        eng.run(hops_per_step * long_steps, presim=False, seed=SEED)
+        eng.sync()
+        out['long_launch'] = dict(kmc_steps_per_launch=long_steps, kernel_ms=eng.last_kernel_ms(),
+                                  hops_per_s_this_rank=R * hops_per_step * long_steps / (eng.last_kernel_ms() * 1e-3))
     if rccl is not None:
         eng.comm_destroy(rccl[1])
     eng.close()
@@ -377,6 +380,7 @@ def main():
     ap.add_argument('--config', type=int, default=5, choices=(1, 2, 3, 4, 5),
                     help='BASELINE.json config to run: 5 (default) is the metric\'s workload; 1-4 are its parity-test cases')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-long-launch', action='store_true', help='skip the informational 32-step launch after the timed region')
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 200 if args.config == 4 else 2000

@@ -10,10 +10,10 @@ mkdir -p $OUT
 (cd $ROOT && python3 -m kmc_amd.build --source-sha256) > $OUT/source_sha256.txt
 cd /tmp
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-long-launch"
 # the trace pass runs 400 + 20 steps (the launch groups need a few steps to drift apart, and the
 # first launches are cold); the counter passes below serialise the kernels anyway and take 6 + 2
-timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 400 --warmup 20 --no-cpu-baseline > $OUT/trace.log 2>&1
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 400 --warmup 20 --no-cpu-baseline --no-long-launch > $OUT/trace.log 2>&1
 echo trace done
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 echo fetch done
