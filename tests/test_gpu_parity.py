@@ -384,18 +384,21 @@ def test_any_size_q_kernel_equals_block_sum_kernel(kmc, tables, nx, ny, mode):
     assert q[11].sum() > 0 and not q[7].any()
 
 
-def test_dense_table_that_does_not_factor(kmc, tables, dense):
+@pytest.mark.parametrize('nx,ny,kernels', [(64, 64, (3, 2)), (30, 30, (4, 1)), (37, 53, (4,)), (70, 66, (0, 1))],
+                         ids=['64x64-q64-lds64', '30x30-q-blocksum', '37x53-q', '70x66-big-global'])
+def test_dense_table_that_does_not_factor(kmc, tables, dense, nx, ny, kernels):
     """A user table (kmc_set_hex_table) need not depend on 13 key bits per direction only: the
-    engine must notice and keep the dense gather; trajectories still match the oracle."""
+    engine must notice and keep the dense gather; trajectories still match the oracle.  Every kernel family
+    has a dense variant (template parameter COMPACT = false) or gathers from the dense table anyway."""
     rs = np.random.RandomState(5)
     dense2 = dense * (1.0 + 0.25 * rs.rand(*dense.shape))        # same zeros, key-dependent values
     R, hp, hs = 3, 700, 1300
-    occ = np.stack([(rs.rand(64, 64) < c).astype(np.int8) for c in (0.3, 0.5, 0.7)])
+    occ = np.stack([(rs.rand(nx, ny) < c).astype(np.int8) for c in (0.3, 0.5, 0.7)])
     d_pre = np.stack([rs.rand(R, hp), np.ones((R, hp))], axis=-1)
     d_sim = rs.rand(R, hs, 2)
     oracle = [_oracle_run(occ[r], dense2, 'hex_ref', d_pre[r], d_sim[r], None) for r in range(R)]
-    for which in (3, 2):                                         # both 64 x 64 kernels have a dense variant
-        with kmc.KMCEngine(R, 64, 64) as eng:
+    for which in kernels:
+        with kmc.KMCEngine(R, nx, ny) as eng:
             eng.set_hop_kernel(which=which)
             eng.set_base_table(tables[0]['base512_normcons'], kmc.tables.dumbbell_rate())
             assert eng.table_is_compact()
