@@ -612,6 +612,16 @@ static int dev_pool(kmc_ctx* c, size_t bytes, void** out)
     *out = c->pool;
     return KMC_OK;
 }
+// The bulk getters (kmc_get_rates: a 201 MB staging chunk, kmc_get_distances: 134 MB at 4096 x 64 x 64) give their
+// staging buffer back: the pool keeps at most KMC_POOL_KEEP bytes between calls.  Called after the stream is idle.
+#define KMC_POOL_KEEP ((size_t)8 << 20)
+static void dev_pool_trim(kmc_ctx* c)
+{
+    if (c->pool && c->pool_cap > KMC_POOL_KEEP) {
+        hipFree(c->pool);
+        c->pool = nullptr; c->pool_cap = 0;
+    }
+}
 static void* host_pool(kmc_ctx* c, size_t bytes)
 {
     if (c->hpool_cap < bytes) {
@@ -869,7 +879,7 @@ int kmc_set_hop_kernel(kmc_ctx* c, int which)
 int kmc_set_replica_offset(kmc_ctx* c, uint64_t offset)
 {
     CTXCHK(c);
-    if (offset + (uint64_t)c->R > 0xFFFFFFFFull)
+    if (offset > 0xFFFFFFFFull - (uint64_t)c->R)           // (not offset + R > ...: that sum wraps for offsets near 2^64)
         return fail(c, KMC_EINVAL, "kmc_set_replica_offset: offset + replicas must fit 32 bits (the Philox counter word)");
     c->rid_base = (uint32_t)offset;
     return KMC_OK;
@@ -1065,6 +1075,7 @@ int kmc_get_rates(kmc_ctx* c, double* P)
         HIPCHK(c, hipMemcpyAsync(P + s0 * 6, d, m * 48, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    dev_pool_trim(c);
     return KMC_OK;
 }
 
@@ -1663,6 +1674,7 @@ int kmc_get_distances(kmc_ctx* c, double a, double* matrix)
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(matrix, d, Rn * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    dev_pool_trim(c);
     return KMC_OK;
 }
 

@@ -243,18 +243,23 @@ class KMCEngine:
         """Everything a run continues from, as numpy arrays (np.savez(path, **eng.checkpoint()) is a checkpoint file):
         the arrays the reference's kmc_step takes and returns (hex_LiCoO2_kmc.py:470, :539) -- lattice, rate matrix
         (as the keys it is a function of), distance_lattice, total_time, hop_histogram -- and each replica's hop count,
-        which is its position in the Philox stream.  The chosen-barrier statistics are diagnostics and start afresh."""
+        which is its position in the Philox stream -- and the replica offset, because the streams are keyed by the global
+        replica id (set_replica_offset).  The chosen-barrier statistics are diagnostics and start afresh."""
         sc, st = self.scalars(), self.status()
         if st['status'].any():
             raise ReplicaStopped(-4, 'checkpoint: replicas have stopped (status %r)' % np.unique(st['status']))
         return dict(nx=np.int64(self.nx), ny=np.int64(self.ny), lattice=self.get_lattice(), keys=self.get_keys(),
-                    displacements=self.get_displacements(), time=sc['time'], hist=sc['hist'], hops_done=st['hops_done'])
+                    displacements=self.get_displacements(), time=sc['time'], hist=sc['hist'], hops_done=st['hops_done'],
+                    replica_offset=np.int64(self.replica_offset))
 
     def restore(self, ck):
         """Load a checkpoint() (or the np.load of one) into this engine: same replica count and lattice size;
         the rate table is set separately, as always."""
         if int(ck['nx']) != self.nx or int(ck['ny']) != self.ny or np.asarray(ck['lattice']).shape[0] != self.R:
             raise ValueError('checkpoint is for %d replicas of %d x %d' % (np.asarray(ck['lattice']).shape[0], int(ck['nx']), int(ck['ny'])))
+        # the Philox streams are keyed by offset + local replica: a shard restored at another offset would silently
+        # continue on other streams (checkpoints written before the field existed were all taken at offset 0)
+        self.set_replica_offset(int(ck['replica_offset']) if 'replica_offset' in ck else 0)
         self.set_lattice(ck['lattice'])
         self.set_keys(ck['keys'])
         self.set_displacements(ck['displacements'])

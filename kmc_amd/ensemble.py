@@ -41,9 +41,12 @@ def shard_replicas(conc_points, replicas_per_point, rank=0, world=1):
     conc_points = np.asarray(conc_points, dtype=np.float64)
     if not (0 <= rank < world):
         raise ValueError('rank %d outside world %d' % (rank, world))
+    if replicas_per_point < world:
+        # checked on EVERY rank before anything else: raised only on the ranks whose share is empty, the others would
+        # go on into the all-reduce and wait there for the process-group time-out
+        raise ValueError('%d replicas per concentration cannot be shared by %d ranks (some would receive none)'
+                         % (replicas_per_point, world))
     k0, k1 = rank * replicas_per_point // world, (rank + 1) * replicas_per_point // world
-    if k1 == k0:
-        raise ValueError('rank %d of %d receives no replica of %d per concentration' % (rank, world, replicas_per_point))
     idx = np.tile(np.arange(conc_points.size), k1 - k0)
     return conc_points[idx], idx, k0 * conc_points.size
 

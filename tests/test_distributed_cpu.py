@@ -147,6 +147,11 @@ def test_shard_replicas_is_a_partition_at_any_world_size():
     import pytest
     with pytest.raises(ValueError):
         ensemble.shard_replicas(points, 2, 2, 4)           # a rank without replicas
+    # ... and EVERY rank raises it, also those whose own share is not empty (7 replicas over 8 ranks leave only rank 0
+    # without one): otherwise the others would go on into the all-reduce and wait for the process-group time-out
+    for rank in range(8):
+        with pytest.raises(ValueError):
+            ensemble.shard_replicas(points, 7, rank, 8)
     # seeds of neighbouring lattice sizes are unrelated (seed + dimension would collide with seed + 1, dimension - 1)
     assert ensemble.derive_seed(5, 11) != ensemble.derive_seed(6, 10)
     assert len({ensemble.derive_seed(s, d) for s in range(20) for d in range(20)}) == 400

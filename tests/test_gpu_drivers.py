@@ -196,10 +196,11 @@ def test_dstar_against_the_published_files_master_table():
     """north_star: "D*(x) within reference error bars".  The reference's published D*(x) files (data_run_4_data,
     data_run_3_data; copies under tests/golden/) against this engine on the fold of master_dictionary.p, in the shape the
     reference's own LiCoO2_kmc.out header shows (10 x 10, 100 + 100 cycles).  What holds and is asserted: D* rises by
-    decades with x on the master table, as in the files.  What does NOT hold, measured in profiles/r2_dstar_vs_reference.md
-    and pinned here so that it cannot change silently: every point lies ABOVE the files' mean + error, by 0.4 to 7.7
-    decades -- the files were not produced by the hex path at this revision (which this engine replays bit for bit,
-    test_golden_trajectory) on either committed table: parity with the published D*(x) is unpinned."""
+    decades with x on the master table, as in the files.  What does NOT hold (profiles/r2_dstar_vs_reference.md): every
+    point lies above the files' mean + error, by 0.4 to 7.7 decades -- the files were not produced by the hex path at this
+    revision (which this engine replays bit for bit, test_golden_trajectory) on either committed table.  Parity with the
+    published D*(x) is UNPINNED; the offsets are printed as a record, not asserted: a test that passes
+    only while parity is absent would fail the day it was reached."""
     import kmc_amd
     from kmc_amd import ensemble
     g = os.path.join(os.path.dirname(__file__), 'golden')
@@ -214,8 +215,8 @@ def test_dstar_against_the_published_files_master_table():
     assert d[0.9] > 1e2 * d[0.3] and d[0.9] > d[0.7] > d[0.5]          # the files: 6.4e-12 / 4.9e-19
     for x in xs:
         mean, err = ref[x]
-        assert d[x] > mean + err, (x, d[x], mean, err)
-        assert 0.3 < np.log10(d[x] / mean) < 8.0, (x, d[x], mean)
+        print('x = %.1f: D* = %.3e, published %.3e +- %.3e, log10 ratio %+.2f%s'
+              % (x, d[x], mean, err, np.log10(d[x] / mean), '' if abs(d[x] - mean) > err else '  (inside the bar)'))
 
 
 def test_rccl_allreduce_behind_the_c_abi(base512):

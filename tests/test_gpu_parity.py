@@ -818,14 +818,18 @@ def test_any_size_kernel_two_builds_agree(kmc, tables, dense):
 
 
 # ---------------------------------------------------------------- checkpoint / resume
-@pytest.mark.parametrize('nx,ny,R', [(64, 64, 5), (30, 30, 4), (70, 66, 2)], ids=['q64', 'lds-30x30', 'big-70x66'])
-def test_checkpoint_resume_continues_bit_for_bit(kmc, tables, tmp_path, nx, ny, R):
+@pytest.mark.parametrize('nx,ny,R,offset', [(64, 64, 5, 0), (30, 30, 4, 0), (70, 66, 2, 0), (64, 64, 3, 4096 * 5 + 17)],
+                         ids=['q64', 'lds-30x30', 'big-70x66', 'q64-sharded-rank'])
+def test_checkpoint_resume_continues_bit_for_bit(kmc, tables, tmp_path, nx, ny, R, offset):
     """The reference's state is the arrays kmc_step takes and returns (hex_LiCoO2_kmc.py:470, :539); saved with
     np.savez and restored into a NEW engine (plus each replica's position in the Philox stream), the run goes on
-    exactly as the uninterrupted one: stale keys, displacement tags, clocks and histograms included."""
+    exactly as the uninterrupted one: stale keys, displacement tags, clocks and histograms included.  The last case is
+    a shard of a larger ensemble (run_ensemble always sets an offset): the checkpoint carries the replica offset the
+    Philox streams are keyed by, and restore() into an engine created at offset 0 must put it back."""
     conc = np.linspace(0.3, 0.7, R)
     seed = 4242
     with make_engine(kmc, tables, R, nx, ny) as a:
+        a.set_replica_offset(offset)
         a.fill_random(conc, 3)
         a.rates_full()
         a.run(300, presim=True, seed=seed)
@@ -841,6 +845,7 @@ def test_checkpoint_resume_continues_bit_for_bit(kmc, tables, tmp_path, nx, ny, 
     with make_engine(kmc, tables, R, nx, ny) as b:
         with np.load(path) as ck:
             b.restore(ck)
+        assert b.replica_offset == offset
         b.run(500, presim=False, seed=seed)
         b.run(77, presim=False, seed=seed)
         sc, st = b.scalars(), b.status()
@@ -882,3 +887,5 @@ def test_replica_offset_makes_sharding_invisible(kmc, tables, nx, ny, R, hops):
     with make_engine(kmc, tables, 4, 8) as eng:
         with pytest.raises(kmc.engine.KMCError):
             eng.set_replica_offset(2 ** 32 - 2)
+        with pytest.raises(kmc.engine.KMCError):
+            eng.set_replica_offset(2 ** 64 - 1)         # offset + R wraps 64 bits
