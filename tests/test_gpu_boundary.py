@@ -62,7 +62,7 @@ def boundary_run(rep, n_hops, presim, rs):
         elif kind == 2:
             rho = np.nextafter(cdf[k], 2.0)
             if rho > cdf[-1]:                                  # beyond the last entry: the reference's IndexError (B4),
-                rho, kind = cdf[k], 0                          # covered by test_selection_edges
+                rho, kind = cdf[k], 0                          # covered by test_draw_above_the_cdf
         elif kind == 3:
             rho = cdf[k - 1] if k > 0 else cdf[k]
         elif kind == 4:
@@ -70,7 +70,7 @@ def boundary_run(rep, n_hops, presim, rs):
         else:
             rho = rs.rand() * cdf[-1]
         if not rho > 0.0:                                      # rho == 0 "hops" entry 0 whatever its rate (B4): its own
-            rho, kind = cdf[k], 0                              # test, test_gpu_parity.py::test_selection_edge_cases
+            rho, kind = cdf[k], 0                              # test, test_gpu_parity.py::test_selection_edges
         draws[h, 0] = rho
         done, sel, _ = rep.run(draws[h:h + 1], presim)
         assert done == 1
@@ -142,20 +142,23 @@ def test_draws_on_the_cdf(kmc, base_tables, dense_tables, case, force):
             assert n_boundary <= st['n_exact'][0] <= hp + hs
 
 
-def test_selection_edges(kmc, base_tables, dense_tables):
-    """B4: rho == 0 returns index 0 whatever its rate; rho above cdf[-1] is the reference's IndexError: the replica
-    stops with status 1 at that hop, every kernel family."""
+def test_draw_above_the_cdf(kmc, base_tables, dense_tables):
+    """B4 on the master fold: rho one ulp above cdf[-1] is the reference's IndexError: the replica stops with status 1 at
+    that hop, every kernel family.  (rho == 0: tests/test_gpu_parity.py::test_selection_edges.)"""
     dense = dense_tables['master']
     for (nx, ny, which) in [(64, 64, 3), (30, 30, 4), (30, 30, 1), (70, 66, 0), (70, 66, 1)]:
         rs = np.random.RandomState(nx + which)
         occ = (rs.rand(nx, ny) < 0.5).astype(np.int8)
         rep = CO.Replica(occ, dense)
-        P4 = rep.P.reshape(nx, ny, 1, 6)
-        top = (np.cumsum(P4) / np.sum(P4))[-1]
         draws = np.stack([rs.rand(8), np.ones(8)], axis=1)
-        draws[5, 0] = np.nextafter(max(top, 1.0), 2.0)
-        done, sel, _ = rep.run(draws, True)
+        done, sel5, _ = rep.run(draws[:5], True)
         assert done == 5
+        P4 = rep.P.reshape(nx, ny, 1, 6)                       # the state the sixth draw meets
+        top = (np.cumsum(P4) / np.sum(P4))[-1]
+        draws[5, 0] = np.nextafter(top, 2.0)
+        done, _, _ = rep.run(draws[5:], True)
+        assert done == 0
+        sel = sel5
         with kmc.KMCEngine(1, nx, ny) as eng:
             eng.set_base_table(base_tables['base512_master'], kmc.tables.dumbbell_rate())
             eng.set_hop_kernel(which=which)
