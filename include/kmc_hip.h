@@ -207,8 +207,14 @@ int kmc_table_is_compact(kmc_ctx* ctx);
 /* Choice of hop kernel (tests compare them): which = 0 the default for the lattice size and replica count;
  * 1 the generic kernel (any-size LDS kernel, or the global-memory kernel for large lattices); for 64 x 64
  * replicas 2 = the 8-replicas-per-CU kernel (kmc_hop_lds64.h), 3 = the 16-per-CU kernel (kmc_hop_q64.h);
- * the default is 3.  No counterpart in the reference. */
+ * the default is 3; 4 = that layout for lattices of 8 ... 64 rows and columns other than 64 x 64 (the default there);
+ * 5 = the one-replica-per-CU kernel (kmc_hop_lat.h: rates, weights and fresh keys of every site in LDS), which is
+ * also what 0 picks when the context holds at most 256 replicas of 8 ... 64 rows and columns and the rate table's
+ * distinct values fit its 1024-entry palette.  No counterpart in the reference. */
 int kmc_set_hop_kernel(kmc_ctx* ctx, int which);
+/* Name of the hop kernel the next kmc_run would launch ("hop_q64_kernel", "hop_lat_kernel<any>", ...): what
+ * bench.py reports beside its timings.  A static string; never NULL.  No counterpart in the reference. */
+const char* kmc_hop_kernel_name(kmc_ctx* ctx);
 /* Launch groups of the LDS-resident hop kernels (lattices up to 64 x 64).  mode 2: every run is launched as two
  * kernels over the two halves of the replicas, each on a stream of its own, and consecutive runs are not joined
  * (a group's next launch waits for that group's last one only), so one group's start-up, write-back and tail

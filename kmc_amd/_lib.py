@@ -64,6 +64,7 @@ SIGNATURES = {
     'kmc_lds_bytes': (C.c_int, [_ctx]),
     'kmc_table_is_compact': (C.c_int, [_ctx]),
     'kmc_set_hop_kernel': (C.c_int, [_ctx, C.c_int]),
+    'kmc_hop_kernel_name': (C.c_char_p, [_ctx]),
     'kmc_set_launch_groups': (C.c_int, [_ctx, C.c_int]),
     'kmc_run_span_ms': (C.c_int, [_ctx, C.c_int, _fp, C.POINTER(C.c_int)]),
     'kmc_debug_stamps': (C.c_int, [_ctx, _i64p]),

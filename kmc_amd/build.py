@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'kmc_hip.hip')
 OUT = os.path.join(HERE, 'libkmc_hip.so')
-DEPS = [SRC] + [os.path.join(HERE, 'csrc', f) for f in ('kmc_device.h', 'kmc_hop_lds.h', 'kmc_hop_lds64.h', 'kmc_hop_q64.h', 'kmc_hop_global.h', 'kmc_hop_big.h', 'kmc_exact_par.h')] + \
+DEPS = [SRC] + [os.path.join(HERE, 'csrc', f) for f in ('kmc_device.h', 'kmc_hop_lds.h', 'kmc_hop_lds64.h', 'kmc_hop_q64.h', 'kmc_hop_lat.h', 'kmc_hop_global.h', 'kmc_hop_big.h', 'kmc_exact_par.h')] + \
        [os.path.join(os.path.dirname(HERE), 'include', 'kmc_hip.h')]
 # -enable-ipra=0: the hop kernels call their (rare) exact path as a real function; with inter-procedural
 # register allocation the callee's large clobber set makes the kernels spill scalar registers inside the

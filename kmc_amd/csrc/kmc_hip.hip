@@ -19,6 +19,7 @@
 #include "kmc_hop_lds.h"
 #include "kmc_hop_lds64.h"
 #include "kmc_hop_q64.h"
+#include "kmc_hop_lat.h"
 #include "kmc_hop_global.h"
 #include "kmc_hop_big.h"
 
@@ -26,6 +27,7 @@ using namespace kmc;
 
 #define KMC_TABLE_ROWS (1u << 18)
 #define KMC_EV_RING 64
+#define KMC_LAT_AUTO_MAX 256      // hop_lat_kernel is the default up to one replica per CU
 
 // ======================================================================
 // context
@@ -39,6 +41,13 @@ struct kmc_ctx {
     bool q64_auto;         // what kmc_set_hop_kernel(ctx, 0) picks
     bool qany_ok, qany;    // 8 <= nx, ny <= 64, not 64 x 64: hop_q64_kernel<., true> (the 16-per-CU layout at any size)
     void* xscratch;        // [R][Q64_XSCRATCH] exact-path scratch of hop_q64_kernel
+    // hop_lat_kernel (kmc_hop_lat.h): one replica per CU, everything a hop reads in LDS.  lat_mode: 0 = automatic
+    // (taken when the replicas fit one per CU and the table's distinct rates fit the palette), 1 = forced
+    // (kmc_set_hop_kernel(ctx, 5)), -1 = never.  pal_state: 0 = palette not built for the current table, 1 = built,
+    // -1 = the table holds more than LAT_PAL_MAX distinct rates.
+    bool lat_ok; int lat_mode, pal_state, n_pal;
+    LatWP* wp;             // [2^18] {W, palette indices} (lazy)
+    double* pal;           // [LAT_PAL_MAX]
     bool big_ok, use_big;  // larger lattices whose bitmaps fit LDS: kmc_hop_big.h (else kmc_hop_global.h)
     BigGeom geom;
     double* hier;          // [R][geom.hier_doubles] sum tree of hop_big_kernel (lazy, zeroed once)
@@ -588,6 +597,28 @@ __global__ __launch_bounds__(256) void diffusion_finalize_kernel(const long long
     dj[r] = pref * dj2 / n_atoms;
 }
 
+// WP[key] = {W[key], the six rates of row `key` as indices into the sorted palette} for hop_lat_kernel.
+__global__ __launch_bounds__(256) void lat_wp_build_kernel(const double* __restrict__ table, const double* __restrict__ wsum,
+                                                           const double* __restrict__ pal, int n_pal, LatWP* __restrict__ wp,
+                                                           int* __restrict__ bad)
+{
+    const uint32_t key = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long rp = 0;
+    for (int d = 0; d < 6; ++d) {
+        const double v = table[(size_t)key * 6 + d];
+        int idx = 0;
+        if (v != 0.0) {
+            int lo = 1, hi = n_pal - 1;                 // pal[1 .. n_pal) ascending
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (pal[mid] < v) lo = mid + 1; else hi = mid; }
+            idx = lo;
+            if (!(pal[idx] == v)) atomicAdd(bad, 1);
+        }
+        rp |= (unsigned long long)idx << (10 * d);
+    }
+    LatWP o; o.w = wsum[key]; o.rp = rp;
+    wp[key] = o;
+}
+
 // Scratch of kmc_diffusion_noalloc: the per-replica integer sums of msd_kernel ([R][4] i64), which kmc_diffusion
 // keeps in a buffer it allocates per call.  One array per GPU the library runs on (2 MiB), held until the process
 // ends.  Host code never uses this NAME as an address: kmc_create asks hipGetSymbolAddress for the array's address
@@ -727,6 +758,11 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     c->qany_ok = c->lds_path && !c->lds64 && nx >= 8 && ny >= 8;
     c->qany = c->qany_ok;
     if (c->lds64 || c->qany_ok) CREATE_CHK(hipMalloc(&c->xscratch, (size_t)c->R * Q64_XSCRATCH));
+    c->lat_ok = c->lds64 || c->qany_ok;
+    if (c->lat_ok) {
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_LDS_BYTES));
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_LDS_BYTES));
+    }
     if (c->lds_path) {
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, K64_LDS_BYTES));
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, K64_LDS_BYTES));
@@ -763,7 +799,7 @@ int kmc_destroy(kmc_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     void* bufs[] = {c->occ, c->keys, c->tags, c->table, c->wsum, c->time_total, c->step_time, c->gamma, c->hist,
                     c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel, c->w_g, c->tcompact, c->tcompact2, c->hier, c->xscratch,
-                    c->coll_buf, c->pool};
+                    c->coll_buf, c->pool, c->wp, c->pal};
     for (void* b : bufs) if (b) hipFree(b);
     free(c->hpool);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -866,12 +902,27 @@ int kmc_lds_bytes(kmc_ctx* c)
 int kmc_set_hop_kernel(kmc_ctx* c, int which)
 {
     CTXCHK(c);
-    if (which < 0 || which > 4) return fail(c, KMC_EINVAL, "kmc_set_hop_kernel: which must be 0 ... 4");
+    if (which < 0 || which > 5) return fail(c, KMC_EINVAL, "kmc_set_hop_kernel: which must be 0 ... 5");
+    if (which == 5 && !c->lat_ok)
+        return fail(c, KMC_EINVAL, "kmc_set_hop_kernel: the one-replica-per-CU kernel takes lattices of 8 ... 64 rows and columns");
+    c->lat_mode = which == 5 ? 1 : (which == 0 ? 0 : -1);
+    if (which == 5) which = 0;
     c->lds64 = c->lds_path && c->nx == 64 && c->ny == 64 && which != 1 && which != 4;
     c->qany = c->qany_ok && (which == 4 || which == 0);
     c->q64 = c->lds64 && (which == 3 || (which == 0 && c->q64_auto));
     c->use_big = c->big_ok && which != 1;
     return KMC_OK;
+}
+
+const char* kmc_hop_kernel_name(kmc_ctx* c)
+{
+    if (!c) return "none";
+    if (!c->lds_path) return c->use_big ? "hop_big_kernel" : "hop_global_kernel";
+    if (c->lat_ok && c->pal_state >= 0 && (c->lat_mode == 1 || (c->lat_mode == 0 && c->R <= KMC_LAT_AUTO_MAX && c->split != 2)))
+        return c->lds64 ? "hop_lat_kernel" : "hop_lat_kernel<any>";
+    if (c->qany) return "hop_q64_kernel<any>";
+    if (c->lds64) return c->q64 ? "hop_q64_kernel" : "hop_lds64_kernel";
+    return "hop_lds_kernel";
 }
 
 // The Philox streams (random fill, per-hop draws) are keyed by (seed, global replica id, counter): a context
@@ -904,6 +955,58 @@ static int build_compact(kmc_ctx* c)
 
 int kmc_table_is_compact(kmc_ctx* c) { return c && c->have_compact ? 1 : 0; }
 
+// The tables of hop_lat_kernel: the palette of the rate table's distinct values (<= LAT_PAL_MAX, 0.0 first) and
+// WP[key] = {W[key], the row's six palette indices}.  Built on first use for the current table: the table comes
+// back to the host once (12.6 MB), its values go through a small open-addressing set.
+static int ensure_lat_tables(kmc_ctx* c)
+{
+    if (c->pal_state != 0) return KMC_OK;
+    const size_t n_ent = (size_t)KMC_TABLE_ROWS * 6;
+    uint64_t* h = (uint64_t*)host_pool(c, n_ent * 8);
+    if (!h) return fail(c, KMC_EINVAL, "kmc_run: out of host memory (palette)");
+    HIPCHK(c, hipMemcpyAsync(h, c->table, n_ent * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint32_t SLOTS = 8192;
+    static const uint64_t EMPTY = ~0ull;               // a NaN pattern: never a rate
+    uint64_t set[SLOTS];
+    for (uint32_t k = 0; k < SLOTS; ++k) set[k] = EMPTY;
+    double pal[LAT_PAL_MAX];
+    int n_pal = 0;
+    pal[n_pal++] = 0.0;                                // index 0 = rate 0: what lanes without an entry read
+    set[0] = 0;                                        // (hash of +0.0 below is 0)
+    bool ok = true;
+    for (size_t e = 0; e < n_ent && ok; ++e) {
+        const uint64_t b = h[e];
+        uint32_t k = (uint32_t)((b * 0x9E3779B97F4A7C15ull) >> 51);          // 13 bits
+        while (set[k] != b) {
+            if (set[k] == EMPTY) {
+                if (n_pal == LAT_PAL_MAX) { ok = false; break; }
+                set[k] = b;
+                memcpy(&pal[n_pal++], &b, 8);
+                break;
+            }
+            k = (k + 1) & (SLOTS - 1);
+        }
+    }
+    if (!ok) { c->pal_state = -1; return KMC_OK; }
+    std::sort(pal + 1, pal + n_pal);                   // a deterministic order (the indices never leave the device)
+    for (int k = n_pal; k < LAT_PAL_MAX; ++k) pal[k] = 0.0;
+    if (!c->pal) HIPCHK(c, hipMalloc((void**)&c->pal, LAT_PAL_MAX * 8));
+    if (!c->wp) HIPCHK(c, hipMalloc((void**)&c->wp, (size_t)KMC_TABLE_ROWS * sizeof(LatWP)));
+    HIPCHK(c, hipMemcpyAsync(c->pal, pal, LAT_PAL_MAX * 8, hipMemcpyHostToDevice, c->stream));
+    int* flag = reinterpret_cast<int*>(c->scratch_d);
+    HIPCHK(c, hipMemsetAsync(flag, 0, 4, c->stream));
+    lat_wp_build_kernel<<<KMC_TABLE_ROWS / 256, 256, 0, c->stream>>>(c->table, c->wsum, c->pal, n_pal, c->wp, flag);
+    HIPCHK(c, hipGetLastError());
+    int bad = 0;
+    HIPCHK(c, hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (bad) return fail(c, KMC_ESTATE, "palette build: %d table entries not found in the palette", bad);
+    c->n_pal = n_pal;
+    c->pal_state = 1;
+    return KMC_OK;
+}
+
 int kmc_set_base_table(kmc_ctx* c, const double* base512, double dumbbell)
 {
     CTXCHK(c);
@@ -917,6 +1020,7 @@ int kmc_set_base_table(kmc_ctx* c, const double* base512, double dumbbell)
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_table = true;
+    c->pal_state = 0;
     return build_compact(c);
 }
 
@@ -929,6 +1033,7 @@ int kmc_set_hex_table(kmc_ctx* c, const double* table)
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_table = true;
+    c->pal_state = 0;
     return build_compact(c);
 }
 
@@ -1173,6 +1278,18 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
     if (!c->lds_path && !c->use_big && c->nx > 4096)
         return fail(c, KMC_EINVAL, "kmc_run: nx = %d exceeds the 4096 rows the global-memory hop kernel keeps in LDS", c->nx);
     if (n_hops == 0) return KMC_OK;
+    // (decided before anything is staged: building the palette uses the context's small scratch buffer)
+    // (an explicit request for launch groups, kmc_set_launch_groups(ctx, 2), keeps the kernels that have them)
+    bool use_lat = c->lat_ok && c->lat_mode >= 0 && (c->lat_mode == 1 || (c->R <= KMC_LAT_AUTO_MAX && c->split != 2));
+    if (use_lat) {
+        if (int rc = ensure_lat_tables(c)) return rc;
+        if (c->pal_state != 1) {
+            if (c->lat_mode == 1)
+                return fail(c, KMC_ESTATE, "kmc_run: the rate table holds more than %d distinct rates: the one-replica-per-CU "
+                            "kernel (kmc_set_hop_kernel 5) cannot hold its palette in LDS", LAT_PAL_MAX);
+            use_lat = false;
+        }
+    }
     const size_t Rh = (size_t)c->R * (size_t)n_hops;
     if (draws) {
         if (c->draws_cap < Rh * 2) {
@@ -1320,6 +1437,25 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         HIPCHK(c, hipMemcpyAsync(dorder, h, (size_t)c->R * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         p.order = dorder;
+    }
+    if (use_lat) {
+        LatParams lp;
+        lp.h = p; lp.wp = c->wp; lp.pal = c->pal;
+        c->run_groups[slot] = 1;
+        time_begin(c);
+        HIPCHK(c, hipEventRecord(c->run_ev[slot][0][0], c->stream));
+        if (c->lds64) hop_lat_kernel<false><<<c->R, 64, LAT_LDS_BYTES, c->stream>>>(lp);
+        else hop_lat_kernel<true><<<c->R, 64, LAT_LDS_BYTES, c->stream>>>(lp);
+        HIPCHK(c, hipEventRecord(c->run_ev[slot][0][1], c->stream));
+        time_end(c);
+        ++c->run_launches;
+        HIPCHK(c, hipGetLastError());
+        if (sel_out) {
+            HIPCHK(c, hipMemcpyAsync(sel_out, c->sel, Rh * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        if (draws) HIPCHK(c, hipStreamSynchronize(c->stream));
+        return KMC_OK;
     }
     if (split) {
         if (c->need_fork) {

@@ -290,9 +290,15 @@ class KMCEngine:
     def set_hop_kernel(self, generic=False, which=None):
         """Choose the hop kernel (tests): generic=True / which=1 the any-size kernel with block sums in LDS; for
         64 x 64 replicas which=2 the 8-replicas-per-CU kernel (kmc_hop_lds64.h), which=3 the 16-per-CU one
-        (kmc_hop_q64.h); which=4 the 16-per-CU layout for 8 ... 64 rows and columns other than 64 x 64; which=0 the
-        default (3 at 64 x 64, 4 where it applies)."""
+        (kmc_hop_q64.h); which=4 the 16-per-CU layout for 8 ... 64 rows and columns other than 64 x 64; which=5 the
+        one-replica-per-CU kernel (kmc_hop_lat.h); which=0 the default (5 up to 256 replicas of 8 ... 64 rows and
+        columns, else 3 at 64 x 64, 4 where it applies)."""
         self._chk(self._lib.kmc_set_hop_kernel(self._ctx, int(which) if which is not None else int(bool(generic))))
+
+    @property
+    def hop_kernel_name(self):
+        """The hop kernel the next run() launches."""
+        return self._lib.kmc_hop_kernel_name(self._ctx).decode()
 
     def set_debug(self, force_exact=False, margin_scale=1.0):
         """force_exact: every hop through the exact replay of the reference's selection (tests).  2 = the same, but the

@@ -202,9 +202,11 @@ def test_golden_trajectory(kmc, tables, dense, dense_master, path, force_exact):
 @pytest.mark.parametrize('force_exact', [False, True], ids=['certified', 'exact'])
 @pytest.mark.parametrize('name,which', [('n64_x05', 1), ('n64_x05', 2), ('n64_x05', 3), ('n30_x05_master', 1), ('n30_x05_master', 4),
                                         ('n30_x05', 1), ('n30_x05', 4), ('n8x12_x05', 4),
-                                        ('n70x66_x04_master', 0), ('n70x66_x04_master', 1)],
+                                        ('n70x66_x04_master', 0), ('n70x66_x04_master', 1),
+                                        ('n64_x05', 5), ('n30_x05_master', 5), ('n30_x05', 5), ('n8x12_x05', 5), ('n10_x03_master', 5)],
                          ids=['n64-generic', 'n64-lds64', 'n64-q64', 'n30master-generic', 'n30master-q', 'n30-generic', 'n30-q', 'n8x12-q',
-                              'n70x66master-big', 'n70x66master-global'])
+                              'n70x66master-big', 'n70x66master-global', 'n64-lat', 'n30master-lat', 'n30-lat', 'n8x12-lat',
+                              'n10master-lat'])
 def test_reference_trajectory_every_kernel_family(kmc, tables, dense, dense_master, name, which, force_exact):
     """The reference-generated trajectories at BASELINE's lattice sizes through EVERY hop kernel that can take them
     (kmc_set_hop_kernel), certified and with every hop forced through the exact replay: selections, lattice, tags,
@@ -277,7 +279,8 @@ def test_random_ensemble_vs_oracle(kmc, tables, dense, cfg):
     oracle = [_oracle_run(occ[r], dense, mode, d_pre[r], d_sim[r], conc[r]) for r in range(R)]
     # 64 x 64 has two kernels (16 replicas per CU, the default, and 8): both; 8 ... 64 rows and columns: the 16-per-CU
     # layout (the default) and the any-size kernel with block sums in LDS
-    for which in ((3, 2) if (nx, ny) == (64, 64) else ((4, 1) if min(nx, ny) >= 8 else (0,))):
+    # (5: the one-replica-per-CU kernel, kmc_hop_lat.h -- what a context of up to 256 replicas takes by default)
+    for which in ((3, 2, 5) if (nx, ny) == (64, 64) else ((4, 1, 5) if min(nx, ny) >= 8 else (0,))):
         _ensemble_vs_oracle(kmc, tables, cfg, which, occ, d_pre, d_sim, oracle)
 
 
@@ -327,7 +330,7 @@ def test_lds64_kernel_equals_generic_kernel(kmc, tables, mode):
     R, hp, hs, seed = 72, 4096 + 37, 10000, 0xC0FFEE
     conc = np.repeat(np.linspace(0.1, 0.9, 9), 8)
     out = []
-    for which in (3, 2, 1):                      # q64, lds64, generic
+    for which in (3, 2, 1, 5):                   # q64, lds64, generic, one-per-CU
         with make_engine(kmc, tables, R, 64, 64, mode) as eng:
             eng.set_hop_kernel(which=which)
             eng.fill_random(conc, 99)
@@ -341,17 +344,19 @@ def test_lds64_kernel_equals_generic_kernel(kmc, tables, mode):
             out.append((i1, i2, i3, eng.get_lattice(), eng.get_keys(), eng.get_displacements(), sc['hist'], st['status'],
                         sc['time'], sc['step_time'], sc['gamma'], st['n_exact'],
                         np.stack(list(eng.barrier_stats().values()))))
-    q64, lds64, generic = out
+    q64, lds64, generic, lat = out
     for a, b in zip(lds64, generic):
         assert np.array_equal(a, b)
-    for k in range(8):                           # integer state: exact
-        assert np.array_equal(q64[k], generic[k])
-    for k in (8, 9, 10):                         # clocks, gamma: a different (fixed) summation order
-        np.testing.assert_allclose(q64[k], generic[k], rtol=1e-13)
-    # barrier statistics: the exact path evaluates the reference's cancelling expression (S5), and the
-    # two kernels do not send the same hops through it
-    np.testing.assert_allclose(q64[12], generic[12], rtol=1e-5)
-    assert lds64[11].sum() > 0 and q64[11].sum() > 0 and not q64[7].any()
+    for other in (q64, lat):
+        for k in range(8):                           # integer state: exact
+            assert np.array_equal(other[k], generic[k])
+        for k in (8, 9, 10):                         # clocks, gamma: a different (fixed) summation order
+            np.testing.assert_allclose(other[k], generic[k], rtol=1e-13)
+        # barrier statistics: the exact path evaluates the reference's cancelling expression (S5), and the
+        # two kernels do not send the same hops through it
+        np.testing.assert_allclose(other[12], generic[12], rtol=1e-5)
+        assert other[11].sum() > 0 and not other[7].any()
+    assert lds64[11].sum() > 0
 
 
 @pytest.mark.parametrize('nx,ny,mode', [(30, 30, 'hex_ref'), (37, 53, 'obj_ref'), (61, 35, 'full'), (12, 9, 'hex_ref')],
@@ -363,7 +368,7 @@ def test_any_size_q_kernel_equals_block_sum_kernel(kmc, tables, nx, ny, mode):
     R, hp, hs, seed = 45, 1000 + 37, 12000, 0xFEED
     conc = np.repeat(np.linspace(0.1, 0.9, 9), 5)
     out = []
-    for which in (4, 1):
+    for which in (4, 1, 5):
         with make_engine(kmc, tables, R, nx, ny, mode) as eng:
             eng.set_hop_kernel(which=which)
             eng.fill_random(conc, 5)
@@ -376,15 +381,18 @@ def test_any_size_q_kernel_equals_block_sum_kernel(kmc, tables, nx, ny, mode):
             sc, st = eng.scalars(), eng.status()
             out.append((i1, i2, i3, eng.get_lattice(), eng.get_keys(), eng.get_displacements(), sc['hist'], st['status'],
                         sc['time'], sc['step_time'], sc['gamma'], st['n_exact']))
-    q, blk = out
-    for k in range(8):
-        assert np.array_equal(q[k], blk[k])
-    for k in (8, 9, 10):
-        np.testing.assert_allclose(q[k], blk[k], rtol=1e-13)
-    assert q[11].sum() > 0 and not q[7].any()
+    q, blk, lat = out
+    for other in (q, lat):
+        if other is lat and min(nx, ny) < 8:
+            continue
+        for k in range(8):
+            assert np.array_equal(other[k], blk[k])
+        for k in (8, 9, 10):
+            np.testing.assert_allclose(other[k], blk[k], rtol=1e-13)
+        assert other[11].sum() > 0 and not other[7].any()
 
 
-@pytest.mark.parametrize('nx,ny,kernels', [(64, 64, (3, 2)), (30, 30, (4, 1)), (37, 53, (4,)), (70, 66, (0, 1))],
+@pytest.mark.parametrize('nx,ny,kernels', [(64, 64, (3, 2, 0)), (30, 30, (4, 1, 0)), (37, 53, (4,)), (70, 66, (0, 1))],
                          ids=['64x64-q64-lds64', '30x30-q-blocksum', '37x53-q', '70x66-big-global'])
 def test_dense_table_that_does_not_factor(kmc, tables, dense, nx, ny, kernels):
     """A user table (kmc_set_hex_table) need not depend on 13 key bits per direction only: the
@@ -457,8 +465,8 @@ def test_philox_stream_run_matches_injected(kmc, tables, dense):
 
 
 # ---------------------------------------------------------------- edges
-@pytest.mark.parametrize('nx,ny,which', [(10, 10, 0), (64, 64, 3), (64, 64, 2), (70, 66, 0)],
-                         ids=['lds-10x10', 'q64', 'lds64', 'big-70x66'])
+@pytest.mark.parametrize('nx,ny,which', [(10, 10, 0), (64, 64, 3), (64, 64, 2), (70, 66, 0), (64, 64, 5), (10, 10, 4), (7, 9, 0)],
+                         ids=['lat-10x10', 'q64', 'lds64', 'big-70x66', 'lat', 'q-10x10', 'lds-7x9'])
 def test_selection_edges(kmc, tables, dense, nx, ny, which):
     """rho == 0 picks index 0 (searchsorted left); rho above cumsum[-1]/gamma is the
     reference's IndexError -> the replica stops with KMC_ST_OVERFLOW; a lattice
@@ -722,7 +730,7 @@ def test_full_size_ensemble_two_kernels(kmc, tables, dense):
 
 
 # ---------------------------------------------------------------- launch groups
-@pytest.mark.parametrize('n,which', [(64, 3), (64, 2), (30, 0)], ids=['q64', 'lds64', 'lds-30x30'])
+@pytest.mark.parametrize('n,which', [(64, 3), (64, 2), (30, 4), (30, 1)], ids=['q64', 'lds64', 'q-30x30', 'lds-30x30'])
 def test_launch_groups_equal_one_launch(kmc, tables, n, which):
     """kmc_set_launch_groups: a run launched as two kernels over the two halves of the replicas, runs not
     joined in between, is the same computation replica by replica -- every output bit-identical to one launch
