@@ -760,8 +760,9 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     if (c->lds64 || c->qany_ok) CREATE_CHK(hipMalloc(&c->xscratch, (size_t)c->R * Q64_XSCRATCH));
     c->lat_ok = c->lds64 || c->qany_ok;
     if (c->lat_ok) {
-        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_LDS_BYTES));
-        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_LDS_BYTES));
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_LDS_BYTES));
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_LDS_BYTES));
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_LDS_BYTES));
     }
     if (c->lds_path) {
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, K64_LDS_BYTES));
@@ -1444,8 +1445,9 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         c->run_groups[slot] = 1;
         time_begin(c);
         HIPCHK(c, hipEventRecord(c->run_ev[slot][0][0], c->stream));
-        if (c->lds64) hop_lat_kernel<false><<<c->R, 64, LAT_LDS_BYTES, c->stream>>>(lp);
-        else hop_lat_kernel<true><<<c->R, 64, LAT_LDS_BYTES, c->stream>>>(lp);
+        if (c->lds64) hop_lat_kernel<false, true><<<c->R, 64, LAT_LDS_BYTES, c->stream>>>(lp);
+        else if (lat_cls_ok(c->ny, c->window_mode)) hop_lat_kernel<true, true><<<c->R, 64, LAT_LDS_BYTES, c->stream>>>(lp);
+        else hop_lat_kernel<true, false><<<c->R, 64, LAT_LDS_BYTES, c->stream>>>(lp);
         HIPCHK(c, hipEventRecord(c->run_ev[slot][0][1], c->stream));
         time_end(c);
         ++c->run_launches;

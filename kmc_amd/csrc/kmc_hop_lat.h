@@ -65,7 +65,28 @@ __device__ __noinline__ void exact_select_lat(const unsigned char* smem, const d
     }, table, n, rho, sh);
 }
 
-template <bool ANY>
+// first set bit of a wave mask, 63 if there is none (s_ff1_i32_b64 returns -1 for zero; __ffsll() - 1 costs a compare and
+// a select more, three times a hop)
+__device__ __forceinline__ int ff1_63(unsigned long long m)
+{
+    int r;
+    asm("s_ff1_i32_b64 %0, %1" : "=s"(r) : "s"(m));
+    return r & 63;
+}
+
+// ANY = false: 64 x 64.  ANY = true: any 8 <= nx, ny <= 64 in the same 64 x 72 planes (sites beyond the lattice hold W = 0
+// and are never selected or refreshed); site numbers in memory are row * ny + column.
+// CLS: the refresh maps the window's columns to lanes by their class (column mod 8), see the hop loop; possible when the
+// <= 6 columns of a window always fall in distinct classes: ny a multiple of 8, or ny mod 8 >= the widest window of the
+// window mode (a window that wraps round the lattice's edge then still meets each class once).  Chosen by the host
+// (lat_cls_ok); otherwise lane c takes window column c and the window's rows are re-summed from LDS.
+__host__ __device__ inline bool lat_cls_ok(int ny, int window_mode)
+{
+    const int m = ny & 7, widest = window_mode == 0 ? 5 : 6;
+    return m == 0 || m >= widest;
+}
+
+template <bool ANY, bool CLS>
 __global__ __launch_bounds__(64)
 void hop_lat_kernel(LatParams lp)
 {
@@ -175,9 +196,22 @@ void hop_lat_kernel(LatParams lp)
     const uint32_t at_and = (lane < 32) ? ~at_bit : ~0u;
     const uint32_t at_or = (lane >= 32) ? at_bit : 0u;
     const uint32_t rp_sh = lane < 6 ? 10u * (uint32_t)lane : 60u;       // lanes >= 6 read index 0 (rate 0)
-    const int wm_ext = p.window_mode == 1 ? 0 : -1;    // all-ones mask: the window extends along the hop
-    const int wm_ni0 = p.window_mode == 0 ? 4 : 5;
-    const int wm_nj0 = p.window_mode == 0 ? 4 : (p.window_mode == 1 ? 6 : 5);
+    // the geometry of a hop in direction d (:503-504) and of its refresh window (:444-453; the three window modes as in
+    // the other kernels: i_lo = i - 2 + ext * min(di, 0), n_i = ni0 + ext * |di|), packed in lane d: one lane read and
+    // six scalar bit-field extracts per hop instead of ~25 scalar instructions
+    int geo;
+    {
+        const int wm_ext = p.window_mode == 1 ? 0 : -1;    // all-ones mask: the window extends along the hop
+        const int wm_ni0 = p.window_mode == 0 ? 4 : 5;
+        const int wm_nj0 = p.window_mode == 0 ? 4 : (p.window_mode == 1 ? 6 : 5);
+        const int d = lane < 6 ? lane : 0;
+        const int di = ((2310 >> (2 * d)) & 3) - 1;          // {1, 0, -1, -1, 0, 1}
+        const int dj = ((105 >> (2 * d)) & 3) - 1;           // {0, 1, 1, 0, -1, -1}
+        const int min_di = di < 0 ? di : 0, min_dj = dj < 0 ? dj : 0;
+        const int ilo = -2 + (wm_ext & min_di), n_i = wm_ni0 + (wm_ext & di & 1);
+        const int jlo = -2 + (wm_ext & min_dj), n_j = wm_nj0 + (wm_ext & dj & 1);
+        geo = (di & 3) | ((dj & 3) << 2) | ((ilo & 7) << 4) | ((jlo & 7) << 7) | (n_i << 10) | (n_j << 13);
+    }
     const double mfac = p.mfac;
     const unsigned long long ok_mask = p.force_exact != 0 ? 0ull : ~0ull;
     const bool presim = p.presim != 0;
@@ -237,17 +271,18 @@ void hop_lat_kernel(LatParams lp)
             }
             const double M = __hiloint2double(M_hi, M_lo);
             // ---- row ------------------------------------------------------
-            const unsigned long long mr = ballot64(rowpre >= t);
-            const int i = (__ffsll((long long)mr) - 1) & 63;
+            const int i = ff1_63(ballot64(rowpre >= t));
             const double base_i = readlane_f64(rowex, i);
-            // ---- site: the row's 64 W, one scan --------------------------------
+            // ---- site: the row's 64 W (and palette words, used after the pick), one scan -----------
             const double wv = W_l[i * LAT_STRIDE + lane];
+            const unsigned long long rp_row = RP_l[i * LAT_STRIDE + lane];
             const double wsc = wave_scan_incl_z(wv, sz);
-            const unsigned long long ms = ballot64(base_i + wsc >= t);
-            const int js = (__ffsll((long long)ms) - 1) & 63;
+            const int js = ff1_63(ballot64(base_i + wsc >= t));       // no site reaches t: 63, and nothing certifies
             const double lo_site = readlane_f64(base_i + dpp_f64<0x138, 0xF>(wsc), js);
             // ---- direction: the site's six palette entries on lanes 0..5 -------------
-            const unsigned long long rpw = RP_l[i * LAT_STRIDE + js];
+            const uint32_t rp_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rp_row, js);
+            const uint32_t rp_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rp_row >> 32), js);
+            const unsigned long long rpw = ((unsigned long long)rp_hi << 32) | rp_lo;
             const uint32_t pi = (uint32_t)(rpw >> rp_sh) & 1023u;
             const double rate = PAL_l[pi];
             double rs = rate + dpp_f64<0x111, 0xF>(rate);
@@ -257,13 +292,13 @@ void hop_lat_kernel(LatParams lp)
             const double ape = lo_site + dpp_f64<0x111, 0xF>(rs);
             const bool ok_l = (ap - t >= M) & (t - ape >= M) & (rate > 0.0);
             const unsigned long long md = ballot64(ap >= t) & 0x3Full;
-            const int dl = (__ffsll((long long)md) - 1) & 63;
+            const int dl = ff1_63(md);
             const unsigned long long mok = ballot64(ok_l);
-            unsigned long long cert = md & mok & (0ull - md) & ok_mask & (ms != 0ull ? ~0ull : 0ull);
+            unsigned long long cert = md & (0ull - md) & mok & ok_mask;         // the lowest set bit of md, certified
             asm("" : "+s"(cert));
             int pnum_lo = __builtin_amdgcn_readlane(__double2loint(rate), dl);
             int pnum_hi = __builtin_amdgcn_readlane(__double2hiint(rate), dl);
-            int j = js, d = dl, i_sel = i;
+            int j = js, d = dl & 7, i_sel = i;
             int exact_flag = 0;
             if (cert == 0ull && !ex_have) { need_exact = true; break; }      // the chunk ends here
             if (ex_have) {
@@ -281,9 +316,11 @@ void hop_lat_kernel(LatParams lp)
             }
             const int ii = i_sel;
             const int idx = (ii * ny + j) * 6 + d;
-            // ---- update (:518-535) -------------------------------------------
-            const int di = ((2310 >> (2 * d)) & 3) - 1;          // {1, 0, -1, -1, 0, 1}
-            const int dj = ((105 >> (2 * d)) & 3) - 1;           // {0, 1, 1, 0, -1, -1}
+            // ---- update (:518-535): the hop's geometry, packed per direction in lane d of `geo` ---------
+            const int gw = __builtin_amdgcn_readlane(geo, d);
+            const int di = __builtin_amdgcn_sbfe(gw, 0, 2), dj = __builtin_amdgcn_sbfe(gw, 2, 2);
+            const int i_lo = ii + __builtin_amdgcn_sbfe(gw, 4, 3), j_lo = j + __builtin_amdgcn_sbfe(gw, 7, 3);
+            const int n_i = (int)__builtin_amdgcn_ubfe((uint32_t)gw, 10, 3), n_j = (int)__builtin_amdgcn_ubfe((uint32_t)gw, 13, 3);
             const int ie = ii + di, je = j + dj;                 // unwrapped
             const int iw = wrap_i(ie), jw = wrap_j(je);
             const int s_src = ii * LAT_STRIDE + j, s_dst = iw * LAT_STRIDE + jw;
@@ -296,16 +333,35 @@ void hop_lat_kernel(LatParams lp)
                 __hip_atomic_fetch_and(fa, at_and, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 __hip_atomic_fetch_or(fa, at_or, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
-            // ---- windowed refresh (:444-465): lane (a, c) = window row a, window column c ------------
-            const int min_di = di < 0 ? di : 0, min_dj = dj < 0 ? dj : 0;
-            const int i_lo = ii - 2 + (wm_ext & min_di), n_i = wm_ni0 + (wm_ext & di & 1);
-            const int j_lo = j - 2 + (wm_ext & min_dj), n_j = wm_nj0 + (wm_ext & dj & 1);
+            // ---- windowed refresh (:444-465): lane (a, c) = window row a and the window column = c (mod 8), so that
+            // the lane's site is a leaf of ITS class in the row's tree (columns c, c + 8, ... c + 56).  That needs the
+            // window's columns in distinct classes (CLS) -- else lane c takes window column c and the rows are
+            // re-summed from LDS.
             const int i_lo0 = wrap_i(i_lo), j_lo0 = wrap_j(j_lo);
-            int si = i_lo0 + grp_a, sj = j_lo0 + grp_c;
-            if (ANY) { si = si >= nx ? si - nx : si; sj = sj >= ny ? sj - ny : sj; }
-            else { si &= 63; sj &= 63; }
-            const bool inw = (grp_a < n_i) & (grp_c < n_j);
-            const int so = si * LAT_STRIDE + sj;
+            constexpr bool classes = CLS;
+            int si = i_lo0 + grp_a, sj;
+            bool inw = grp_a < n_i;
+            if (!ANY) {
+                const int wcol = (grp_c - j_lo0) & 7;
+                si &= 63; sj = (j_lo0 + wcol) & 63;
+                inw &= wcol < n_j;
+            } else if (classes) {
+                // lane c owns class c: the window column of that class, if there is one -- in the part of the window
+                // before the lattice's edge (j_lo0 + k, k = (c - j_lo0) mod 8) or in the part wrapped to columns 0 .. b - 1
+                // (column c itself) -- else column c, an unchanged leaf of the class
+                si = si >= nx ? si - nx : si;
+                const int k1 = (grp_c - j_lo0) & 7, col1 = j_lo0 + k1;
+                const bool v1 = (k1 < n_j) & (col1 < ny);
+                const int b = j_lo0 + n_j - ny;                  // uniform; <= 0: the window does not wrap
+                sj = v1 ? col1 : grp_c;
+                inw &= v1 | (grp_c < b);
+            } else {
+                si = si >= nx ? si - nx : si;
+                sj = j_lo0 + grp_c; sj = sj >= ny ? sj - ny : sj;
+                inw &= grp_c < n_j;
+            }
+            const int srow = si * LAT_STRIDE;
+            const int so = srow + sj;
             wave_fence();
             uint32_t knew = FR_l[so];
             knew = (knew & LAT_OCC_BIT) ? (knew & 0x3FFFFu) : Q64_VAC;
@@ -317,7 +373,20 @@ void hop_lat_kernel(LatParams lp)
                 asm("" : "+v"(ko));              // one 32-bit value: an SGPR base + VGPR offset load
                 wn = *reinterpret_cast<const LatWP*>(wp_b + ko);
             }
-            // ---- book-keeping that nothing in this hop waits for runs while the gather is in flight
+            // ---- while the gather is in flight: what nothing in this hop waits for, and the unchanged part of the
+            // window rows' sums.  A row's sum is the balanced tree over its 64 W; the lane's own leaf (column oc, the
+            // refreshed site or, for lanes without one, column c) meets its sibling leaf, then the sibling pair, then
+            // the sibling quad of its class: all old values, read now.
+            double sib1 = 0.0, sib2 = 0.0, sib4 = 0.0, leaf = 0.0;
+            if (classes) {
+                const int oc = sj;               // in class c whether refreshed or not
+                const double* wr = W_l + srow;
+                const int c2 = (oc ^ 16) & ~8, c4 = (oc ^ 32) & ~24;
+                leaf = wr[oc];
+                sib1 = wr[oc ^ 8];
+                sib2 = wr[c2] + wr[c2 + 8];
+                sib4 = (wr[c4] + wr[c4 + 8]) + (wr[c4 + 16] + wr[c4 + 24]);
+            }
             writelane5(gam_lo, gam_hi, pn_lo, pn_hi, idx_v, __double2loint(gamma), __double2hiint(gamma),
                        pnum_lo, pnum_hi, idx | exact_flag, hl);
             ++hops;
@@ -332,14 +401,24 @@ void hop_lat_kernel(LatParams lp)
                 const int now_ = (seen ? oow : (64 << 8) + (64 << 16)) + wrap;
                 writelane2(tg_sv, tg_ow, nsv, now_, lm);
             }
-            if (inw) {
-                W_l[so] = wn.w;
-                RP_l[so] = wn.rp;
-            }
-            wave_fence();
             // ---- re-sum the window's rows, re-scan ------------------------------------------------
+            double s;
+            if (classes) {
+                leaf = inw ? wn.w : leaf;
+                s = group8_sum(((leaf + sib1) + sib2) + sib4);
+                if (inw) {
+                    W_l[so] = wn.w;
+                    RP_l[so] = wn.rp;
+                }
+            } else {
+                if (inw) {
+                    W_l[so] = wn.w;
+                    RP_l[so] = wn.rp;
+                }
+                wave_fence();
+                s = row_tree(si);
+            }
             {
-                const double s = row_tree(si);
                 int rel;
                 if (ANY) { rel = lane - i_lo0; rel = rel < 0 ? rel + nx : rel; }
                 else rel = (lane - i_lo) & 63;
@@ -349,6 +428,7 @@ void hop_lat_kernel(LatParams lp)
                 const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(s));
                 rowsum = take ? __hiloint2double(hi, lo) : rowsum;
             }
+            wave_fence();
             rowpre = wave_scan_incl_z(rowsum, sz);
             rowex = dpp_f64<0x138, 0xF>(rowpre);
             gamma = readlane_f64(rowpre, 63);
