@@ -6,9 +6,10 @@
 // kind, and ~110 KB of the CU's LDS and three of its four SIMDs idle.  This kernel spends the idle LDS on
 // everything a hop's dependent chain reads, so that ONE L2 gather per hop is left on it (W and the rates of the
 // <= 36 refreshed sites, a function of their new keys) and the chain is ~40 % fewer instructions:
-//   W    f64 [64][72]   per-site sum of the six rates (row_sum6 of the site's stale table row)
-//   RP   u64 [64][72]   per-site rates as six 10-bit indices into a palette of the table's distinct values
-//                       (the folded tables hold ~800 distinct rates: tables with more than 1024 keep q64)
+//   WR   16 B [64][72]  per site {W, RP}: W = f64 sum of the six rates (row_sum6 of the site's stale table row), RP = the
+//                       rates as six 10-bit indices into a palette of the table's distinct values (the folded tables
+//                       hold ~800 distinct rates: tables with more than 1024 keep q64); one 16-byte read per lane
+//                       fetches a whole row of both
 //   PAL  f64 [1024]     the palette
 //   FR   u32 [64][72]   the site's FRESH 18-bit key (bit 17 - p = occupancy of neighbour p, hex_LiCoO2_kmc.py:423-424)
 //                       and its own occupancy in bit 18, maintained by two LDS atomics per hop: the 18 sites that see
@@ -32,17 +33,19 @@
 namespace kmc {
 
 #define LAT_STRIDE 72
-#define LAT_W 0
-#define LAT_RP (LAT_W + 64 * LAT_STRIDE * 8)
-#define LAT_FR (LAT_RP + 64 * LAT_STRIDE * 8)
+// FR, ST and PAL first: every address the hop loop computes in a register then takes its array's base as the 16-bit
+// immediate offset of the LDS instruction
+#define LAT_FR 0
 #define LAT_ST (LAT_FR + 64 * LAT_STRIDE * 4)
 #define LAT_PAL (LAT_ST + 64 * LAT_STRIDE * 4)
-#define LAT_MISC (LAT_PAL + 1024 * 8)
+#define LAT_WR (LAT_PAL + 1024 * 8)                    // {W, RP} interleaved, 16 B per site
+#define LAT_MISC (LAT_WR + 64 * LAT_STRIDE * 16)
 #define LAT_LDS_BYTES (LAT_MISC + 96)
 #define LAT_PAL_MAX 1024
 #define LAT_OCC_BIT 0x40000u
 
 static_assert(LAT_LDS_BYTES <= 160 * 1024, "one replica per CU");
+static_assert(LAT_WR + 8 < 65536, "immediate offsets of the LDS instructions");
 
 struct __attribute__((aligned(16))) LatWP {
     double w;                    // row_sum6 of the table row
@@ -95,8 +98,7 @@ void hop_lat_kernel(LatParams lp)
     const int r = p.order ? p.order[blockIdx.x + p.r_base] : (int)blockIdx.x + p.r_base, lane = threadIdx.x;
     const int nx = ANY ? p.nx : 64, ny = ANY ? p.ny : 64;
     const int n = ANY ? p.n : 4096;
-    double* W_l = reinterpret_cast<double*>(smem + LAT_W);
-    unsigned long long* RP_l = reinterpret_cast<unsigned long long*>(smem + LAT_RP);
+    LatWP* WR_l = reinterpret_cast<LatWP*>(smem + LAT_WR);
     uint32_t* FR_l = reinterpret_cast<uint32_t*>(smem + LAT_FR);
     uint32_t* ST_l = reinterpret_cast<uint32_t*>(smem + LAT_ST);
     double* PAL_l = reinterpret_cast<double*>(smem + LAT_PAL);
@@ -110,7 +112,7 @@ void hop_lat_kernel(LatParams lp)
 
     // ---- load the replica ------------------------------------------------
     for (int k = lane; k < LAT_PAL_MAX; k += KMC_WAVE) PAL_l[k] = lp.pal[k];
-    for (int k = lane; k < 64 * LAT_STRIDE; k += KMC_WAVE) { FR_l[k] = 0u; ST_l[k] = Q64_VAC; W_l[k] = 0.0; RP_l[k] = 0ull; }
+    for (int k = lane; k < 64 * LAT_STRIDE; k += KMC_WAVE) { FR_l[k] = 0u; ST_l[k] = Q64_VAC; WR_l[k].w = 0.0; WR_l[k].rp = 0ull; }
     wave_fence();
     // fresh keys: every occupied site sets its bit in the 18 sites that see it, and its own occupancy bit
     if (!ANY || lane < ny) {
@@ -141,8 +143,7 @@ void hop_lat_kernel(LatParams lp)
                 if (i0 + q < nx) {
                     const int so = (i0 + q) * LAT_STRIDE + lane;
                     ST_l[so] = k[q];
-                    W_l[so] = v[q].w;
-                    RP_l[so] = v[q].rp;
+                    WR_l[so] = v[q];
                 }
             }
         }
@@ -153,8 +154,8 @@ void hop_lat_kernel(LatParams lp)
     // the sum of row `row` (all 8 lanes of group a receive it): leaves c, c + 8, ... c + 56 per lane as a balanced
     // tree, then the 8-lane tree (group8_sum).  A pure function of the row's W with one fixed association.
     auto row_tree = [&](int row) -> double {
-        const double* w = W_l + row * LAT_STRIDE + grp_c;
-        const double l0 = w[0], l1 = w[8], l2 = w[16], l3 = w[24], l4 = w[32], l5 = w[40], l6 = w[48], l7 = w[56];
+        const LatWP* w = WR_l + row * LAT_STRIDE + grp_c;
+        const double l0 = w[0].w, l1 = w[8].w, l2 = w[16].w, l3 = w[24].w, l4 = w[32].w, l5 = w[40].w, l6 = w[48].w, l7 = w[56].w;
         return group8_sum(((l0 + l1) + (l2 + l3)) + ((l4 + l5) + (l6 + l7)));
     };
     double rowsum = 0.0;                               // lane i: the sum of row i
@@ -274,8 +275,9 @@ void hop_lat_kernel(LatParams lp)
             const int i = ff1_63(ballot64(rowpre >= t));
             const double base_i = readlane_f64(rowex, i);
             // ---- site: the row's 64 W (and palette words, used after the pick), one scan -----------
-            const double wv = W_l[i * LAT_STRIDE + lane];
-            const unsigned long long rp_row = RP_l[i * LAT_STRIDE + lane];
+            const LatWP wr_row = WR_l[i * LAT_STRIDE + lane];
+            const double wv = wr_row.w;
+            const unsigned long long rp_row = wr_row.rp;
             const double wsc = wave_scan_incl_z(wv, sz);
             const int js = ff1_63(ballot64(base_i + wsc >= t));       // no site reaches t: 63, and nothing certifies
             const double lo_site = readlane_f64(base_i + dpp_f64<0x138, 0xF>(wsc), js);
@@ -290,10 +292,9 @@ void hop_lat_kernel(LatParams lp)
             rs += dpp_f64<0x114, 0xF>(rs);
             const double ap = lo_site + rs;
             const double ape = lo_site + dpp_f64<0x111, 0xF>(rs);
-            const bool ok_l = (ap - t >= M) & (t - ape >= M) & (rate > 0.0);
             const unsigned long long md = ballot64(ap >= t) & 0x3Full;
             const int dl = ff1_63(md);
-            const unsigned long long mok = ballot64(ok_l);
+            const unsigned long long mok = ballot64(ap - t >= M) & ballot64(t - ape >= M) & ballot64(rate > 0.0);
             unsigned long long cert = md & (0ull - md) & mok & ok_mask;         // the lowest set bit of md, certified
             asm("" : "+s"(cert));
             int pnum_lo = __builtin_amdgcn_readlane(__double2loint(rate), dl);
@@ -329,7 +330,7 @@ void hop_lat_kernel(LatParams lp)
             {
                 const int ti = wrap_i(ii + at_di + (di & at_end));
                 const int tj = wrap_j(j + at_dj + (dj & at_end));
-                uint32_t* fa = FR_l + (at_on ? ti * LAT_STRIDE + tj : 0);
+                uint32_t* fa = FR_l + (ti * LAT_STRIDE + tj);      // (idle lanes: the point itself, AND ~0, OR 0)
                 __hip_atomic_fetch_and(fa, at_and, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 __hip_atomic_fetch_or(fa, at_or, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
@@ -364,7 +365,11 @@ void hop_lat_kernel(LatParams lp)
             const int so = srow + sj;
             wave_fence();
             uint32_t knew = FR_l[so];
-            knew = (knew & LAT_OCC_BIT) ? (knew & 0x3FFFFu) : Q64_VAC;
+            {
+                // vacant site -> 0x3FFFF: the sign-extended occupancy bit selects (no compare, no VCC)
+                const uint32_t om = (uint32_t)__builtin_amdgcn_sbfe((int)knew, 18u, 1u);
+                knew = ((knew & om) | ~om) & 0x3FFFFu;
+            }
             LatWP wn;
             asm("" : "=v"(wn.w), "=v"(wn.rp));
             if (inw) {
@@ -380,12 +385,12 @@ void hop_lat_kernel(LatParams lp)
             double sib1 = 0.0, sib2 = 0.0, sib4 = 0.0, leaf = 0.0;
             if (classes) {
                 const int oc = sj;               // in class c whether refreshed or not
-                const double* wr = W_l + srow;
+                const LatWP* wr = WR_l + srow;
                 const int c2 = (oc ^ 16) & ~8, c4 = (oc ^ 32) & ~24;
-                leaf = wr[oc];
-                sib1 = wr[oc ^ 8];
-                sib2 = wr[c2] + wr[c2 + 8];
-                sib4 = (wr[c4] + wr[c4 + 8]) + (wr[c4 + 16] + wr[c4 + 24]);
+                leaf = wr[oc].w;
+                sib1 = wr[oc ^ 8].w;
+                sib2 = wr[c2].w + wr[c2 + 8].w;
+                sib4 = (wr[c4].w + wr[c4 + 8].w) + (wr[c4 + 16].w + wr[c4 + 24].w);
             }
             writelane5(gam_lo, gam_hi, pn_lo, pn_hi, idx_v, __double2loint(gamma), __double2hiint(gamma),
                        pnum_lo, pnum_hi, idx | exact_flag, hl);
@@ -406,15 +411,9 @@ void hop_lat_kernel(LatParams lp)
             if (classes) {
                 leaf = inw ? wn.w : leaf;
                 s = group8_sum(((leaf + sib1) + sib2) + sib4);
-                if (inw) {
-                    W_l[so] = wn.w;
-                    RP_l[so] = wn.rp;
-                }
+                if (inw) WR_l[so] = wn;
             } else {
-                if (inw) {
-                    W_l[so] = wn.w;
-                    RP_l[so] = wn.rp;
-                }
+                if (inw) WR_l[so] = wn;
                 wave_fence();
                 s = row_tree(si);
             }
