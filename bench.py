@@ -176,23 +176,115 @@ def host_threads():
 
 
 # ---------------------------------------------------------------------------------------------- counters
-def load_pmc(np, R_local, hops_per_step):
-    """profiles/pmc_current.json (scripts/profile_bench.sh + scripts/summarize_profile.py) if it was taken on the
-    sources this library is built from and on this workload; else (None, reason)."""
+def load_pmc(config, kernel, replicas_per_launch=None):
+    """The entry of profiles/pmc_current.json for this BASELINE config (scripts/pmc_config.sh + scripts/summarize_profile.py)
+    if it was taken on the sources this library is built from, on this kernel and launch shape; else (None, reason)."""
     from kmc_amd import build as kb
     path = os.path.join(ROOT, 'profiles', 'pmc_current.json')
     try:
         with open(path) as f:
-            pj = json.load(f)
-    except OSError:
+            pj = json.load(f).get('configs', {}).get(str(config))
+    except (OSError, ValueError):
         return None, 'profiles/pmc_current.json is missing'
+    if pj is None:
+        return None, 'profiles/pmc_current.json holds no counter pass for config %d' % config
     here = kb.source_sha256()
     if pj.get('source_sha256') != here:
-        return None, 'stale: profiles/pmc_current.json (%s) was taken on sources %s..., this library is built from %s...' % (
+        return None, 'stale: the counter pass %s was taken on sources %s..., this library is built from %s...' % (
             pj.get('tag'), str(pj.get('source_sha256'))[:12], here[:12])
-    if pj.get('hops_per_launch') != hops_per_step:
-        return None, 'profiles/pmc_current.json is for %s hops per launch' % pj.get('hops_per_launch')
+    if kernel.split('<')[0] not in pj.get('kernel', ''):
+        return None, 'the counter pass %s is of %s, this run launches %s' % (pj.get('tag'), pj.get('kernel'), kernel)
+    if replicas_per_launch is not None and pj.get('replicas_per_launch') != replicas_per_launch:
+        return None, 'the counter pass %s is of launches of %s replicas, this run launches %s' % (
+            pj.get('tag'), pj.get('replicas_per_launch'), replicas_per_launch)
     return pj, None
+
+
+LDS_PEAK_B_PER_CLK_CU = 256.0    # MI355X_MICROARCH.md (LDS): 64 banks x 4 B per clock per CU
+N_CU = 256
+# profiles/r2_issue_cost_probe.txt (scripts/probes/valu_rate_probe.hip): shader cycles per instruction per SIMD, from the
+# cheapest class (VOP2 / SALU) to the dearest common one (VOP3, DPP, fp64, lane reads), by waves per SIMD
+ISSUE_CYCLES = {1: (4.69, 5.70), 2: (2.35, 3.74), 3: (1.9, 3.2), 4: (1.67, 2.86)}
+
+
+def build_roofline(config, kernel, k_ms, step_hops, groups, replicas_per_launch, waves_per_simd, simds_used, launch_ms=None, b_hop_ref=None):
+    """The roofline object of the JSON line.  Every fraction is (per-hop counter of the committed PMC pass) x (hops per
+    second measured live with HIP events) / (the resource's peak): VALU busy cycles, LDS bytes and LDS-array cycles,
+    instruction issue, HBM bytes.  The counters are per launch; hops per launch = replicas per launch x hops per replica."""
+    roof = {'bound': 'valu_busy', 'achieved': None, 'peak': simds_used * CLOCK_HZ / 4 / 1e9,
+            'unit': 'G VALU-busy quad-cycles/s (over the %d SIMDs that hold a wave)' % simds_used,
+            'frac': None, 'traffic': None, 'kernel': kernel, 'kernel_ms': k_ms, 'launches_per_step': groups,
+            'hops_per_step_rank0': step_hops, 'waves_per_simd': waves_per_simd, 'simds_used': simds_used,
+            'formula': 'achieved = SQ_ACTIVE_INST_VALU per hop (PMC, quad-cycles summed over waves) x hops per step / kernel_ms; '
+                       'peak = SIMDs holding a wave x 2.4 GHz / 4; kernel_ms = HIP-event span of the timed launches / steps (live)'}
+    if launch_ms is not None:
+        roof['launch_ms'] = launch_ms
+    pj, why = load_pmc(config, kernel, replicas_per_launch)
+    roof['pmc'] = why
+    if pj is None:
+        return roof
+    hops_launch = step_hops / groups                          # the pass ran this workload: same launches
+    hops_s = step_hops / (k_ms * 1e-3)
+    busy_q = pj['active_inst_valu_per_launch'] / hops_launch
+    ach = busy_q * hops_s
+    hbm_step = pj['hbm_bytes_per_launch'] / hops_launch * step_hops
+    insts = {k: pj.get(k + '_insts_per_launch', 0.0) / hops_launch for k in ('valu', 'salu', 'lds', 'vmem_rd', 'vmem_wr', 'smem')}
+    n_inst = sum(insts.values())
+    lo, hi = ISSUE_CYCLES[max(1, min(4, int(round(waves_per_simd))))]
+    per_simd = n_inst * hops_s / simds_used                   # instructions per second per SIMD
+    roof.update(achieved=ach / 1e9, frac=ach / (simds_used * CLOCK_HZ / 4), traffic=int(hbm_step),
+                pmc={'file': 'profiles/pmc_current.json', 'tag': pj.get('tag'), 'source_sha256': pj['source_sha256'],
+                     'replicas_per_launch': pj['replicas_per_launch'], 'hops_per_launch': hops_launch,
+                     'SQ_ACTIVE_INST_VALU_per_hop_quadcycles': busy_q,
+                     'insts_per_hop': insts, 'SQ_WAVE_CYCLES_per_hop_quadcycles': pj.get('wave_cycles_per_launch', 0) / hops_launch,
+                     'SQ_WAIT_ANY_per_hop_quadcycles': pj.get('wait_any_per_launch', 0) / hops_launch,
+                     # share of a SIMD's cycles with the VALU busy while its waves are resident
+                     'valu_busy_while_resident': (waves_per_simd * pj['active_inst_valu_per_launch'] / pj['wave_cycles_per_launch']
+                                                  if pj.get('wave_cycles_per_launch') else None),
+                     'lds_bank_conflict_frac': pj.get('lds_bank_conflict_frac'),
+                     'l2_hit_rate': (pj['l2_hits_per_launch'] / (pj['l2_hits_per_launch'] + pj['l2_misses_per_launch'])
+                                     if pj.get('l2_hits_per_launch') else None),
+                     'pmc_kernel_avg_ms': pj.get('kernel_avg_ms'),
+                     # the clock the chip held DURING the counter passes (GRBM_GUI_ACTIVE / the dispatch's duration in that
+                     # pass) and the duration of a launch in the SQ pass: what reconciles SQ_WAVE_CYCLES with the 2.4 GHz peak
+                     'pmc_clock_ghz': pj.get('pmc_clock_ghz'), 'pmc_launch_ms': pj.get('sq_pass_launch_ms')},
+                issue={'insts_per_hop': n_inst, 'insts_per_s_per_simd': per_simd,
+                       'probe_cycles_per_inst': [lo, hi], 'probe': 'profiles/r2_issue_cost_probe.txt, %d wave(s) per SIMD' % waves_per_simd,
+                       'frac_range': [per_simd * lo / CLOCK_HZ, per_simd * hi / CLOCK_HZ],
+                       'note': 'share of a SIMD\'s cycles its waves need just to ISSUE the hop\'s instructions, between the cheapest '
+                               '(VOP2, SALU) and the dearest common class (VOP3, DPP, fp64, lane reads) of the issue-rate probe'},
+                hbm={'bytes_per_step': int(hbm_step), 'bytes_per_hop': pj['hbm_bytes_per_launch'] / hops_launch,
+                     'GB/s': hbm_step / (k_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'frac': hbm_step / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     'note': 'FETCH_SIZE x 2 (gfx950 correction, upper bound for 16-B gathers) + WRITE_SIZE, separate --pmc passes'})
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'lds_bytes_static.json')) as f:
+            lb = json.load(f)
+        from kmc_amd import build as kb
+        ent = lb['kernels'].get(kernel)
+        if ent and lb.get('source_sha256') == kb.source_sha256():
+            b = ent['lds_array_bytes_per_hop_upper']
+            peak = LDS_PEAK_B_PER_CLK_CU * N_CU * CLOCK_HZ
+            roof['lds'] = {'bytes_per_hop_static_upper': b, 'TB/s': b * hops_s / 1e12, 'peak_TB/s': peak / 1e12, 'frac': b * hops_s / peak,
+                           'array_busy_frac': (pj['lds_idx_active_per_launch'] / hops_launch * hops_s / (N_CU * CLOCK_HZ)
+                                               if pj.get('lds_idx_active_per_launch') else None),
+                           'note': 'bytes: every DS instruction of the hop loop x 64 lanes (scripts/lds_bytes.py, an upper bound); peak = 256 B/clk/CU '
+                                   'x 256 CUs x 2.4 GHz; array_busy_frac = SQ_LDS_IDX_ACTIVE (LDS-array cycles, measured) / (256 CUs x clock)'}
+    except (OSError, ValueError, KeyError):
+        pass
+    if b_hop_ref is not None:
+        roof['traffic_avoided_vs_reference_algorithm'] = b_hop_ref * hops_launch / pj['hbm_bytes_per_launch']
+    # which resource is nearest its peak, and how a wave's resident time splits (SQ_WAVE_CYCLES = issuing + parked on a
+    # wait + stalled at issue): a kernel none of whose resources is near 1 is bound by its waves' dependent chains
+    shares = {'valu_busy': roof['frac'], 'issue': 0.5 * sum(roof['issue']['frac_range']), 'hbm': roof['hbm']['frac']}
+    if roof.get('lds') and roof['lds'].get('array_busy_frac') is not None:
+        shares['lds_array'] = roof['lds']['array_busy_frac']
+    roof['nearest_peak'] = max(shares, key=lambda k: shares[k])
+    roof['shares_of_peak'] = shares
+    if pj.get('wave_cycles_per_launch'):
+        wc = pj['wave_cycles_per_launch']
+        roof['wave_time'] = {'issuing': pj.get('active_inst_any_per_launch', 0) / wc, 'parked_on_a_wait': pj.get('wait_any_per_launch', 0) / wc,
+                             'note': 'SQ_ACTIVE_INST_ANY and SQ_WAIT_ANY over SQ_WAVE_CYCLES (the rest: stalled at issue)'}
+    return roof
 
 
 # ---------------------------------------------------------------------------------------------- one measurement
@@ -277,7 +369,7 @@ def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red
     out = dict(elapsed=elapsed, k_ms=span_ms / n_span, launch_ms=float(np.mean(ev)), groups=groups, R=R,
                n_exact=int(st['n_exact'].sum()), stopped=int((st['status'] != 0).sum()),
                stats=ensemble.finalize(acc, [CONC])[0], fold_ms=fold_ms, rates_ms=rates_ms,
-               hops_per_step=hops_per_step, base512=base512)
+               hops_per_step=hops_per_step, base512=base512, kernel=eng.hop_kernel_name)
     # For information (not `value`): the same kernel when a run is ONE launch of many KMC steps, as ensemble.run_ensemble
     # and the sweep driver make them -- no prologue / write-back / tail per 2048 hops.  After everything that is reported.
     # (--no-long-launch: the profile passes average their counters over the launches of ONE size)
@@ -335,9 +427,49 @@ def measure_other(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torc
     span_ms, groups = eng.run_span_ms(n_span)
     out = dict(elapsed=elapsed, k_ms=span_ms / n_span, groups=groups, R=R, n_exact=int(st['n_exact'].sum()),
                stopped=int((st['status'] != 0).sum()), stats=ensemble.finalize(acc, cfg['conc']), step_hops_rank=int(hops_vec.sum()),
-               lds_bytes=eng.lds_bytes, lds_path=eng.uses_lds_path)
+               lds_bytes=eng.lds_bytes, lds_path=eng.uses_lds_path, kernel=eng.hop_kernel_name,
+               uniform_hops=bool((hops_vec == hops_vec[0]).all()))
     eng.close()
     return out
+
+
+def dropin_rate(np, cfg, n_sim=40):
+    """hops/s of the DROP-IN path itself for config 1: the reference's driver loop (hex_LiCoO2_kmc.py:716-758) written
+    against kmc_amd.hex_LiCoO2_kmc -- kmc_evolve(initialise), presimulation kmc_steps, displacement tags, simulation
+    kmc_steps, one call per reference KMC step, numpy's global RandomState for the draws.  Each call moves the draws up
+    and the lattice, the rate matrix (48 B a site) and the tags back, as the signature demands; the state itself stays on
+    the device between calls."""
+    import kmc_amd.hex_LiCoO2_kmc as K
+    n, x = cfg['n'], cfg['conc'][0]
+    tabs = np.load(os.path.join(ROOT, 'tests', 'golden', 'tables.npz'))
+    K.window_mode = 'hex_ref'
+    K.set_rate_table(tabs['base512_' + cfg['table']])
+    K.mc_lattice_size = [n, n, 1]
+    K.Li_concentration = x
+    np.random.seed(SEED % (2 ** 32))
+    occ = np.zeros(n * n, dtype=np.uint8)
+    occ[np.random.permutation(n * n)[:int(n * n * x)]] = 1
+    lat = np.where(occ.reshape(n, n, 1) == 1, -1.0, 1.0)
+    K.mc_lattice = lat
+    P = K.kmc_evolve(lat, np.zeros((n, n, 1, 6)), 0, 0, True)
+    for _ in range(3):
+        (lat, P) = K.kmc_step(lat, None, P, True)
+    dist = np.tile([-1, 0, 0], (n, n, 1, 1))
+    ii, jj = np.nonzero(lat[:, :, 0] == -1)
+    dist[ii, jj, 0, 0], dist[ii, jj, 0, 1] = ii, jj
+    (lat, dist, _, P, _, _) = K.kmc_step(lat, dist, P, False)          # first simulation call: the tags go up
+    t0 = time.perf_counter()
+    total = 0.0
+    for _ in range(n_sim):
+        (lat, dist, dt, P, _, _) = K.kmc_step(lat, dist, P, False)
+        total += dt
+    wall = time.perf_counter() - t0
+    hops = n_sim * int(n * n * 1 * x)
+    (d_star, _, d_j) = K.get_diffusion_coefficient(dist, [n, n, 1], total, K.lattice_constant, x)
+    K.close()
+    return dict(hops_per_s=hops / wall, kmc_step_calls=n_sim, hops_per_call=int(n * n * 1 * x), ms_per_call=wall / n_sim * 1e3,
+                d_star=float(d_star), what='kmc_amd.hex_LiCoO2_kmc.kmc_step in the reference\'s own loop shape (hex_LiCoO2_kmc.py:745-758), '
+                                           'one call per KMC step, state resident on the device between calls')
 
 
 def d_star_check_run(kmc_amd, np, local_rank, base512, n_replicas=4, sim_steps=40):
@@ -358,6 +490,16 @@ def d_star_check_run(kmc_amd, np, local_rank, base512, n_replicas=4, sim_steps=4
         ds, _, _ = eng.diffusion(CONC)
         return dict(replica_ids=list(range(n_replicas)), occ0=occ0, occ1=eng.get_lattice(), d_star=ds, time=eng.scalars()['time'],
                     presim_hops=hops_per_step, sim_hops=hops_per_step * sim_steps)
+
+
+def occupancy_of(kernel, R):
+    """(waves per SIMD, SIMDs that hold a wave) of a launch of R one-wave replicas of `kernel` on the 256 CUs."""
+    if kernel.startswith('hop_big') or kernel.startswith('hop_global'):
+        return 1, min(R, N_CU) * 4                            # one 256-thread workgroup per lattice: a wave on each SIMD
+    per_cu = 1 if kernel.startswith('hop_lat') else 16
+    waves_cu = max(1, min(per_cu, -(-R // N_CU)))
+    simds = min(R, N_CU * 4) if waves_cu >= 4 else min(R, N_CU * waves_cu)
+    return max(1, waves_cu // 4), simds
 
 
 def shard(total, rank, world):
@@ -442,7 +584,16 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            kern = ('hop_q64_kernel' if cfg['n'] == 64 else 'hop_lds_kernel') if mo['lds_path'] else 'hop_big_kernel'
+            dropin = dropin_rate(np, cfg) if args.config == 1 else None
+            kern = mo['kernel']
+            wps, simds = occupancy_of(kern, mo['R'])
+            if mo['uniform_hops']:
+                roof = build_roofline(args.config, kern, mo['k_ms'], mo['step_hops_rank'], mo['groups'], mo['R'] // mo['groups'], wps, simds)
+            else:
+                roof = {'bound': 'valu_busy', 'achieved': None, 'peak': None, 'unit': None, 'frac': None, 'traffic': None, 'kernel': kern,
+                        'kernel_ms': mo['k_ms'], 'launches_per_step': mo['groups'],
+                        'pmc': 'replicas of this configuration run different hop counts per step: per-hop counters of a launch do not '
+                               'normalise; the kernel is the headline line\'s (--config 5), which carries the roofline'}
             emit({
                 'metric': 'KMC hops/sec, BASELINE config %d (a parity-test case, not the headline workload)' % args.config,
                 'value': hops_all * args.steps / mo['elapsed'], 'unit': 'hops/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -450,9 +601,7 @@ def main():
                 'scaling': 'strong' if cfg['R'] >= world else 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                 'config': {'workload': cfg['what'], 'replicas_total': cfg['R'] if cfg['R'] >= world else cfg['R'] * world,
                            'lattice': [cfg['n'], cfg['n']], 'concentrations': cfg['conc'], 'hops_per_step_all_replicas': hops_all, 'seed': SEED},
-                'roofline': {'bound': 'latency (one wave\'s dependent chain)' if cfg['R'] < 3072 else 'valu_busy', 'achieved': None, 'peak': None, 'unit': None,
-                             'frac': None, 'traffic': None, 'kernel': kern, 'kernel_ms': mo['k_ms'], 'launches_per_step': mo['groups'],
-                             'note': 'no PMC pass is kept for this configuration; the headline line (--config 5) carries the roofline'},
+                'roofline': roof, 'dropin': dropin,
                 'kernel_hops_per_s': mo['step_hops_rank'] / (mo['k_ms'] * 1e-3), 'exact_path_hops': mo['n_exact'],
                 'stopped_replicas': mo['stopped'], 'd_star_by_concentration': [[r['concentration'], r['d_star'], r['error_star']] for r in mo['stats']]})
         return
@@ -480,32 +629,8 @@ def main():
     k_ms = m['k_ms']
     step_hops = R * hops_per_step                            # rank 0's hops per step
     b_hop = algorithmic_bytes_per_hop(N_SIDE)
-    pj, why = load_pmc(np, R, hops_per_step)
-    roof = {'bound': 'valu_busy', 'achieved': None, 'peak': N_SIMD * CLOCK_HZ / 4 / 1e9, 'unit': 'G VALU-busy quad-cycles/s (all SIMDs)',
-            'frac': None, 'traffic': None, 'kernel': 'hop_q64_kernel', 'kernel_ms': k_ms, 'launches_per_step': m['groups'],
-            'launch_ms': m['launch_ms'], 'hops_per_step_rank0': step_hops,
-            'formula': 'achieved = SQ_ACTIVE_INST_VALU per hop (PMC, quad-cycles summed over waves) x hops per step / kernel_ms; '
-                       'peak = 1024 SIMDs x 2.4 GHz / 4; kernel_ms = HIP-event span of the timed launches / steps (live); '
-                       'launch_ms = mean duration of one launch (what rocprofv3 lists)',
-            'pmc': why}
-    if pj is not None:
-        per_hop = pj['hops_per_launch'] * pj['replicas_per_launch']
-        busy_q = pj['active_inst_valu_per_launch'] / per_hop                     # quad-cycles per hop
-        ach = busy_q * step_hops / (k_ms * 1e-3)
-        hbm_step = pj['hbm_bytes_per_launch'] / per_hop * step_hops
-        roof.update(achieved=ach / 1e9, frac=ach / (N_SIMD * CLOCK_HZ / 4), traffic=int(hbm_step),
-                    pmc={'file': 'profiles/pmc_current.json', 'tag': pj.get('tag'), 'source_sha256': pj['source_sha256'],
-                         'replicas_per_launch': pj['replicas_per_launch'],
-                         'SQ_ACTIVE_INST_VALU_per_hop_quadcycles': busy_q,
-                         'SQ_INSTS_VALU_per_hop': pj.get('valu_insts_per_launch', 0) / per_hop,
-                         'SQ_INSTS_SALU_per_hop': pj.get('salu_insts_per_launch', 0) / per_hop,
-                         'valu_busy_while_resident': pj.get('valu_busy_while_resident'),
-                         'lds_bank_conflict_frac': pj.get('lds_bank_conflict_frac'),
-                         'pmc_kernel_avg_ms': pj.get('kernel_avg_ms')},
-                    hbm={'bytes_per_step': int(hbm_step), 'bytes_per_hop': pj['hbm_bytes_per_launch'] / per_hop,
-                         'GB/s': hbm_step / (k_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'frac': hbm_step / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         'note': 'FETCH_SIZE x 2 (gfx950 correction, upper bound for 16-B gathers) + WRITE_SIZE, separate --pmc passes'},
-                    traffic_avoided_vs_reference_algorithm=b_hop * per_hop / pj['hbm_bytes_per_launch'])
+    wps, simds = occupancy_of(m['kernel'], R)
+    roof = build_roofline(5, m['kernel'], k_ms, step_hops, m['groups'], R // m['groups'], wps, simds, launch_ms=m['launch_ms'], b_hop_ref=b_hop)
     roof['reference_algorithm_bytes_per_hop'] = b_hop
     out = {
         'metric': METRIC,

@@ -40,7 +40,8 @@ namespace kmc {
 #define LAT_PAL (LAT_ST + 64 * LAT_STRIDE * 4)
 #define LAT_WR (LAT_PAL + 1024 * 8)                    // {W, RP} interleaved, 16 B per site
 #define LAT_MISC (LAT_WR + 64 * LAT_STRIDE * 16)
-#define LAT_LDS_BYTES (LAT_MISC + 96)
+#define LAT_IDLE (LAT_MISC + 96)                       // u32 [64]: where the idle lanes of the fresh-key atomics point
+#define LAT_LDS_BYTES (LAT_IDLE + 256)
 #define LAT_PAL_MAX 1024
 #define LAT_OCC_BIT 0x40000u
 
@@ -194,6 +195,7 @@ void hop_lat_kernel(LatParams lp)
     const int at_dj = at_on && at_q < 18 ? -kNbJ[at_q < 18 ? at_q : 0] : 0;
     const uint32_t at_bit = at_on ? (at_q < 18 ? 1u << (17 - at_q) : LAT_OCC_BIT) : 0u;
     const int at_end = lane >= 32 ? -1 : 0;            // all ones: this lane works on the end point
+    uint32_t* const at_idle = reinterpret_cast<uint32_t*>(smem + LAT_IDLE) + lane;
     const uint32_t at_and = (lane < 32) ? ~at_bit : ~0u;
     const uint32_t at_or = (lane >= 32) ? at_bit : 0u;
     const uint32_t rp_sh = lane < 6 ? 10u * (uint32_t)lane : 60u;       // lanes >= 6 read index 0 (rate 0)
@@ -330,7 +332,8 @@ void hop_lat_kernel(LatParams lp)
             {
                 const int ti = wrap_i(ii + at_di + (di & at_end));
                 const int tj = wrap_j(j + at_dj + (dj & at_end));
-                uint32_t* fa = FR_l + (ti * LAT_STRIDE + tj);      // (idle lanes: the point itself, AND ~0, OR 0)
+                // (idle lanes AND ~0 / OR 0 into a word of their own: thirteen lanes on ONE address would be serialised)
+                uint32_t* fa = at_on ? FR_l + (ti * LAT_STRIDE + tj) : at_idle;
                 __hip_atomic_fetch_and(fa, at_and, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 __hip_atomic_fetch_or(fa, at_or, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }

@@ -48,13 +48,19 @@ device = 0
 _table = None                    # ('base', vec512, dumbbell) | ('dense', array)
 _engines = {}
 _row_lookup = None
+_host_table = None               # host copy of the dense table (kmc_evolve's window patch), read back once per table
+# What the device of each engine holds after the last kmc_step, as the arrays that call returned: a caller that hands
+# them back unchanged (the reference's loop, hex_LiCoO2_kmc.py:724-758, does exactly that) finds the lattice, the stale
+# keys behind its rate matrix and the displacement tags already there, and the call uploads nothing but its draws.
+# Compared by VALUE (a few hundred KB at 64 x 64), never by identity: an array edited in place is noticed.
+_resident = {}
 
 
 def set_rate_table(source, dumbbell=None):
     """Select the hop-rate table: a path to master_dictionary.p /
     normcons_dictionary.p / hex_dict.p, a dict loaded from one of them, a
     512-vector, or a dense (262144, 6) array."""
-    global _table, _row_lookup
+    global _table, _row_lookup, _host_table
     if isinstance(source, (str, bytes)):
         kind, arr = _tables.load_any(source)
     elif isinstance(source, dict):
@@ -70,7 +76,9 @@ def set_rate_table(source, dumbbell=None):
     for e in _engines.values():
         e.close()
     _engines.clear()
+    _resident.clear()
     _row_lookup = None
+    _host_table = None
 
 
 def _engine_for(nx, ny):
@@ -136,6 +144,7 @@ def get_hex_probability(lattice_point):
     i, j = int(lattice_point[0]), int(lattice_point[1])
     occ = _occ(mc_lattice)
     eng = _engine_for(*occ.shape)
+    _resident.pop(id(eng), None)
     eng.set_lattice(occ[None])
     _, rates = eng.site_probability(0, i % occ.shape[0], j % occ.shape[1])
     return rates
@@ -151,22 +160,31 @@ def kmc_evolve(mc_lattice, hop_probability_matrix, startpoint, endpoint, use_ini
     nx, ny = occ.shape
     eng = _engine_for(nx, ny)
     if use_initialize_mode == True:                                       # noqa: E712
+        _resident.pop(id(eng), None)
         eng.set_lattice(occ[None])
         eng.rates_full()
         return eng.get_rates()[0].reshape(nx, ny, 1, 6)
     # Only the window is re-evaluated (from the current lattice); every other
     # entry of the caller's matrix is left as it is -- stale or not.
+    # On the device: the lattice goes up (nx * ny bytes), the sites are keyed, refresh_window_kernel re-keys the window's
+    # sites with the selected window's geometry, the keys come back (4 bytes a site) and the window's <= 36 rows are taken
+    # from the host copy of the table: no rate matrix is materialised or moved (48 bytes a site).
+    global _host_table
+    _resident.pop(id(eng), None)                   # the device no longer holds what the last kmc_step returned
     eng.set_lattice(occ[None])
     eng.rates_full()
     se = [int(startpoint[0]), int(startpoint[1]), int(endpoint[0]), int(endpoint[1])]
     eng.refresh_window([se])                       # R3 on the device (same sites, same keys)
-    fresh = eng.get_rates()[0]
+    keys = eng.get_keys()[0]
+    if _host_table is None:
+        _host_table = eng.get_hex_table()
     P = np.asarray(hop_probability_matrix)
     Pv = P.reshape(nx, ny, 6)
     i_lo, i_hi, j_lo, j_hi = _window(startpoint, endpoint)
     for i in range(i_lo, i_hi):
         for j in range(j_lo, j_hi):
-            Pv[i % nx, j % ny] = fresh[i % nx, j % ny]
+            k = keys[i % nx, j % ny]
+            Pv[i % nx, j % ny] = _host_table[k] if k != _engine.VACANT_KEY else 0.0
     return hop_probability_matrix
 
 
@@ -197,21 +215,28 @@ def kmc_step(mc_lattice, input_distance_lattice, input_hop_probability_matrix, u
     nx, ny = occ.shape
     n_hops = int(mc_lattice_size[0] * mc_lattice_size[1] * mc_lattice_size[2] * Li_concentration)   # :484
     eng = _engine_for(nx, ny)
-    keys = _keys_from_rates(eng, occ, input_hop_probability_matrix)
-    eng.set_keys(keys[None])
     presim = bool(use_presimulation_mode)
+    res = _resident.pop(id(eng), None)
+    P_in = np.asarray(input_hop_probability_matrix)
+    if not (res is not None and np.array_equal(res['occ'], occ) and res['P'].shape == P_in.shape and np.array_equal(res['P'], P_in)):
+        # not what the last call left on the device: derive the stale keys from the caller's matrix, upload
+        keys = _keys_from_rates(eng, occ, input_hop_probability_matrix)
+        eng.set_keys(keys[None])
+        res = None
     if not presim:
-        d = np.asarray(input_distance_lattice).reshape(nx, ny, 3).astype(np.int64)
-        w_i = np.round(d[..., 2] / 100.0).astype(np.int64)            # :574 (valid for |w_j| <= 49)
-        tags = np.stack([d[..., 0], d[..., 1], w_i, d[..., 2] - 100 * w_i], axis=-1).astype(np.int32)
-        eng.set_displacements(tags[None])
+        d_in = np.asarray(input_distance_lattice)
+        if not (res is not None and res.get('dist') is not None and res['dist'].shape == d_in.shape and np.array_equal(res['dist'], d_in)):
+            d = d_in.reshape(nx, ny, 3).astype(np.int64)
+            w_i = np.round(d[..., 2] / 100.0).astype(np.int64)            # :574 (valid for |w_j| <= 49)
+            tags = np.stack([d[..., 0], d[..., 1], w_i, d[..., 2] - 100 * w_i], axis=-1).astype(np.int32)
+            eng.set_displacements(tags[None])
     # the reference draws rho (:490) and, outside presimulation, the clock draw
     # (:530) from numpy's global stream, in this order, once per hop
     draws = np.random.uniform(0, 1, size=(n_hops, 1 if presim else 2))
     if presim:
         draws = np.concatenate([draws, np.ones((n_hops, 1))], axis=1)
     hist0 = eng.scalars()['hist'][0].copy()
-    bar0 = eng.barrier_stats()['count'][0]
+    bar0 = eng.barrier_stats()['count'][0] if not presim else 0
     eng.run(n_hops, presim=presim, draws=draws[None])
     st = eng.status()
     if st['status'][0] & 1:
@@ -226,9 +251,12 @@ def kmc_step(mc_lattice, input_distance_lattice, input_hop_probability_matrix, u
     sc = eng.scalars()
     hop_histogram += (sc['hist'][0] - hist0)                           # module global (:30, :535)
     if presim:
+        _resident[id(eng)] = dict(occ=new_occ, P=P.copy(), dist=None)
         return (lat, P)
     t = eng.get_reference_tags()[0].reshape(nx, ny, 1, 3)
     dist = np.array(t, dtype=np.asarray(input_distance_lattice).dtype)
+    # (the tags are resident only if the caller's dtype holds them exactly, which any integer or float dtype does)
+    _resident[id(eng)] = dict(occ=new_occ, P=P.copy(), dist=dist.copy())
     bar = eng.barrier_stats()
     if bar['count'][0] == bar0:
         # every selected index was 0: the reference's chosen_barrier is unbound (:495, :539)
@@ -295,3 +323,4 @@ def close():
     for e in _engines.values():
         e.close()
     _engines.clear()
+    _resident.clear()

@@ -104,6 +104,53 @@ def test_functional_dropin_replays_reference_run(name, normcons_pickle):
     K.close()
 
 
+def test_dropin_resident_state_is_checked_by_value(normcons_pickle, tabs):
+    """kmc_step keeps the lattice, the stale keys and the tags on the device between calls when the caller hands back
+    what the last call returned (the reference's loop does).  The check is by value: an array edited in place between
+    two calls -- here an atom moved by hand and the rate matrix rebuilt, then one rate row overwritten -- is noticed and
+    the run still follows the oracle from the caller's arrays (hex_LiCoO2_kmc.py:470-542)."""
+    import kmc_amd.hex_LiCoO2_kmc as K
+    dense = O.build_hex_table(tabs['base512_normcons'])
+    nx = ny = 12
+    K.window_mode = 'hex_ref'
+    K.set_rate_table(normcons_pickle)
+    K.mc_lattice_size = [nx, ny, 1]
+    K.Li_concentration = 0.5
+    rs = np.random.RandomState(3)
+    occ = np.zeros(nx * ny, dtype=np.uint8)
+    occ[rs.permutation(nx * ny)[:72]] = 1
+    occ = occ.reshape(nx, ny)
+    lat = np.where(occ == 1, -1.0, 1.0).reshape(nx, ny, 1)
+    K.mc_lattice = lat
+    P = K.kmc_evolve(lat, np.zeros((nx, ny, 1, 6)), 0, 0, True)
+    rep = CO.Replica(occ, dense)
+
+    def step():
+        nonlocal lat, P
+        st = np.random.get_state()
+        d = np.random.uniform(0, 1, size=(72, 1))
+        np.random.set_state(st)
+        (lat, P) = K.kmc_step(lat, None, P, True)
+        rep.run(np.concatenate([d, np.ones((72, 1))], axis=1), True)
+        assert np.array_equal((lat[:, :, 0] == -1).astype(np.uint8), rep.occ) and np.array_equal(P[:, :, 0, :], rep.P)
+    np.random.seed(11)
+    step()
+    step()                                                   # resident: nothing but the draws goes up
+    # an atom moved by hand, rates rebuilt by the caller: lattice and matrix differ from what the device holds
+    (i0, j0), (i1, j1) = np.argwhere(rep.occ == 1)[0], np.argwhere(rep.occ == 0)[0]
+    lat[i0, j0, 0], lat[i1, j1, 0] = 1.0, -1.0
+    P = K.kmc_evolve(lat, P, 0, 0, True)
+    rep = CO.Replica((lat[:, :, 0] == -1).astype(np.uint8), dense)
+    step()
+    step()
+    # a rate row overwritten in place with another row of the table (a stale entry the caller made up)
+    i2, j2 = np.argwhere(rep.occ == 1)[5]
+    P[i2, j2, 0, :] = dense[0x2AAAA]
+    rep.P[i2, j2] = dense[0x2AAAA]
+    step()
+    step()
+
+
 def test_functional_kmc_evolve_window(normcons_pickle, tabs):
     """Windowed kmc_evolve touches the reference's window only and keeps stale rows."""
     import kmc_amd.hex_LiCoO2_kmc as K
