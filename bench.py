@@ -61,6 +61,32 @@ def algorithmic_bytes_per_hop(n_side, window_sites=WINDOW_SITES):
 
 
 # ---------------------------------------------------------------------------------------------- launcher
+class Watchdog:
+    """A rank that does not get through a rendezvous (init_process_group, the RCCL communicator) must not sit in it for
+    the process group's 20 minutes while its peers have died: `with Watchdog(what, seconds):` ends the process with exit
+    code 3 and a line on stderr if the block has not finished in time.  The process is ended, never re-executed."""
+    def __init__(self, what, seconds):
+        import threading
+        self.what, self.seconds = what, seconds
+        self.timer = threading.Timer(seconds, self.fire)
+        self.timer.daemon = True
+
+    def fire(self):
+        sys.stderr.write('bench.py: rank %s: %s did not complete in %d s; exiting\n' % (os.environ.get('RANK', '0'), self.what, self.seconds))
+        sys.stderr.flush()
+        os._exit(3)
+
+    def __enter__(self):
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+
+
+RENDEZVOUS_TIMEOUT_S = int(os.environ.get('KMC_BENCH_RENDEZVOUS_TIMEOUT', '180'))
+
+
 def launch_ranks(n, argv):
     """Parent of a self-launched N-rank run.  Touches no GPU and imports no torch."""
     import socket
@@ -329,9 +355,10 @@ def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red
     rccl = None
     if args.collective == 'rccl' and dist is not None:
         # the engine's own communicator: rank 0 makes the id, torch.distributed only carries its 128 bytes
-        box = [kmc_amd.KMCEngine.comm_unique_id() if dist.get_rank() == 0 else None]
-        dist.broadcast_object_list(box, src=0, device=red_dev)
-        rccl = (eng, eng.comm_create(box[0], dist.get_world_size(), dist.get_rank()))
+        with Watchdog('kmc_comm_create', RENDEZVOUS_TIMEOUT_S):
+            box = [kmc_amd.KMCEngine.comm_unique_id() if dist.get_rank() == 0 else None]
+            dist.broadcast_object_list(box, src=0, device=red_dev)
+            rccl = (eng, eng.comm_create(box[0], dist.get_world_size(), dist.get_rank()))
     ensemble.all_reduce_acc(np.zeros((1, len(ensemble.ACC_FIELDS))), red_dev, rccl)   # ... and of the collective (RCCL set-up)
     eng.sync()
 
@@ -556,10 +583,14 @@ def main():
                          % (world, torch.cuda.device_count()))
             torch.cuda.set_device(local_rank)
             red_dev = torch.device('cuda', local_rank)
-            dist.init_process_group('nccl', device_id=red_dev, timeout=datetime.timedelta(minutes=20))
+            with Watchdog('init_process_group(nccl)', RENDEZVOUS_TIMEOUT_S):
+                dist.init_process_group('nccl', device_id=red_dev, timeout=datetime.timedelta(minutes=20))
+                dist.barrier()                           # the communicator itself is made on first use: make it here
         else:
             local_rank = local_rank % max(torch.cuda.device_count(), 1)
-            dist.init_process_group(backend, timeout=datetime.timedelta(minutes=20))
+            with Watchdog('init_process_group(%s)' % backend, RENDEZVOUS_TIMEOUT_S):
+                dist.init_process_group(backend, timeout=datetime.timedelta(minutes=20))
+                dist.barrier()
 
     import numpy as np
     import kmc_amd

@@ -173,3 +173,21 @@ def test_bench_self_launch_reports_a_failing_rank():
     else:
         assert out.stdout.strip() == ''
         assert 'bench.py: rank' in out.stderr and 'no CPU backend' in out.stderr
+
+
+def test_rank_whose_peer_never_arrives_exits_in_time():
+    """bench.py's rendezvous watchdog: rank 0 of a two-rank job whose rank 1 never starts must not wait out the process
+    group's 20 minutes -- it exits with code 3 and says what did not complete."""
+    import socket
+    import time
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, KMC_BENCH_BACKEND='gloo', KMC_BENCH_RENDEZVOUS_TIMEOUT='6', RANK='0', LOCAL_RANK='0', WORLD_SIZE='2',
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 3, (out.returncode, out.stderr[-500:])
+    assert 'did not complete' in out.stderr and 'init_process_group' in out.stderr
+    assert time.time() - t0 < 200

@@ -241,3 +241,30 @@ def test_rccl_allreduce_behind_the_c_abi(base512):
         with pytest.raises(kmc_amd.engine.KMCError):
             eng.comm_create(uid, 2, 2)
         eng.comm_destroy(comm)
+
+
+def test_bench_two_ranks_on_one_gpu_equal_one_rank():
+    """The N > 1 host path of bench.py on the GPU box: `bench.py --gpus 2` with KMC_BENCH_BACKEND=gloo (two rank processes
+    sharing the one GPU; the NCCL leg needs two devices).  The line must report n_gpus = 2 and carry the other scaling's
+    numbers; and because the Philox streams are keyed by the global replica id, the 2-rank STRONG run (2048 replicas per
+    rank) is the same ensemble as a 1-rank run of 4096: D* equal to 1e-12 (the all-reduce adds in another order)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ['--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-long-launch', '--replicas', '512']
+    env = dict(os.environ, KMC_BENCH_BACKEND='gloo', KMC_BENCH_RENDEZVOUS_TIMEOUT='120')
+    two = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--scaling', 'strong'] + common,
+                         env=env, capture_output=True, text=True, timeout=420)
+    assert two.returncode == 0, two.stderr[-2000:]
+    line2 = json.loads(two.stdout.strip().splitlines()[-1])
+    one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--scaling', 'strong'] + common,
+                         env=env, capture_output=True, text=True, timeout=420)
+    assert one.returncode == 0, one.stderr[-2000:]
+    line1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert line2['n_gpus'] == 2 and line2['scaling'] == 'strong' and line2['config']['replicas_total'] == 512
+    assert line2['config']['replicas_rank0'] == 256
+    assert line2['other_scaling']['scaling'] == 'weak' and line2['other_scaling']['replicas_total'] == 1024
+    assert line2['value'] > 0 and line2['other_scaling']['value'] > 0
+    assert abs(line2['d_star_mean'] - line1['d_star_mean']) <= 1e-12 * abs(line1['d_star_mean'])
+    assert line2['stopped_replicas'] == 0 and line1['stopped_replicas'] == 0
