@@ -209,8 +209,8 @@ int kmc_table_is_compact(kmc_ctx* ctx);
  * replicas 2 = the 8-replicas-per-CU kernel (kmc_hop_lds64.h), 3 = the 16-per-CU kernel (kmc_hop_q64.h);
  * the default is 3; 4 = that layout for lattices of 8 ... 64 rows and columns other than 64 x 64 (the default there);
  * 5 = the one-replica-per-CU kernel (kmc_hop_lat.h: rates, weights and fresh keys of every site in LDS), which is
- * also what 0 picks when the context holds at most 256 replicas of 8 ... 64 rows and columns and the rate table's
- * distinct values fit its 1024-entry palette.  No counterpart in the reference. */
+ * also what 0 picks when the context holds at most 512 replicas of 8 ... 64 rows and columns (one replica per CU up to
+ * 256, two beyond) and the rate table's distinct values fit its 1024-entry palette.  No counterpart in the reference. */
 int kmc_set_hop_kernel(kmc_ctx* ctx, int which);
 /* Name of the hop kernel the next kmc_run would launch ("hop_q64_kernel", "hop_lat_kernel<any>", ...): what
  * bench.py reports beside its timings.  A static string; never NULL.  No counterpart in the reference. */

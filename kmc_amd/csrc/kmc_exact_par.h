@@ -158,6 +158,7 @@ __device__ __forceinline__ long long wave_scan_incl_i64(long long x)
 // three, and the replay is bound by exactly those (one CU takes ~0.5 scattered 16-byte requests per cycle) -- and summed;
 // only a tile that holds an event (a binade crossing, a tie, the stop: ~60 of the 1000 tiles of a 1024 x 1024 replay) is
 // read again in the owner layout below, where every thread holds consecutive entries and the event's place can be found.
+#define XP_SYNC() do { if (NW == 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); else __syncthreads(); } while (0)
 template <int NW, int KMC_XP_SITES, bool LEAN, bool STRIPED = false, class KeyFn>     // KMC_XP_SITES = sites per thread and tile
 __device__ __forceinline__ void exact_select_par_impl(KeyFn keys, const double* __restrict__ table,
                                                       int n, double rho, ExactParShared* sh,
@@ -165,7 +166,9 @@ __device__ __forceinline__ void exact_select_par_impl(KeyFn keys, const double* 
 {
     constexpr int XP_THREADS = 64 * NW;
     constexpr long XP_TILE = (long)XP_THREADS * KMC_XP_SITES * 6;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // NW == 1: the caller is ONE wave, possibly of a workgroup that holds other waves doing something else (hop_lat_kernel's
+    // two-replica workgroups): the thread number is the lane and a hand-off needs the memory fence only, not the barrier
+    const int tid = NW == 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef KMC_XP_TRACE
     const unsigned long long xp_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -195,10 +198,10 @@ restart:
             }
             if (lane == 0) sh->chunk_sum[wv] = res;
         }
-        __syncthreads();
+        XP_SYNC();
         if (tid == 0)
             for (int q = 0; q < NW && c0 + q < nfull; ++q) total = total + sh->chunk_sum[q];
-        __syncthreads();
+        XP_SYNC();
     }
     double t_lo = 0.0;                                    // fast form: the lower edge of the band (thread 0)
     if (tid == 0) {
@@ -229,9 +232,9 @@ restart:
             sh->cstar = x;
         }
     }
-    __syncthreads();
+    XP_SYNC();
     XP_TRACE(0, 1); XP_TRACE(5, __builtin_amdgcn_s_memtime() - xp_t0);
-    if (fast && sh->done == 3) { __syncthreads(); fast = false; total = 0.0; goto restart; }
+    if (fast && sh->done == 3) { XP_SYNC(); fast = false; total = 0.0; goto restart; }
     if (sh->done) return;
     const double cstar = sh->cstar;
     const long long two53 = 1LL << 53, two54 = 1LL << 54;
@@ -302,7 +305,7 @@ restart:
                 const long long incl = wave_scan_incl_i64(run);
                 const bool wflag = __builtin_amdgcn_ballot_w64(flag) != 0ull;
                 if (lane == 63) { sh->wave_tot[parity][wv] = incl; sh->wave_flag[parity][wv] = wflag ? 1 : 0; }
-                __syncthreads();
+                XP_SYNC();
                 long long tot = 0;
                 int anyflag = 0;
 #pragma unroll
@@ -379,7 +382,7 @@ restart:
             const long long incl = wave_scan_incl_i64(run);
             const bool wflag = __builtin_amdgcn_ballot_w64(flag) != 0ull;
             if (lane == 63) { sh->wave_tot[parity][wv] = incl; sh->wave_flag[parity][wv] = wflag ? 1 : 0; }
-            __syncthreads();
+            XP_SYNC();
             long long base = A + (incl - run), tot = 0;
             int anyflag = 0;
 #pragma unroll
@@ -395,7 +398,7 @@ restart:
             if (!any) { c = c_end; pos = tile_end; continue; }           // the common tile
             // ---- an event somewhere in the tile: find the first one ----------------------------
             if (tid == 0) sh->ev = KMC_XP_NOEV;
-            __syncthreads();
+            XP_SYNC();
             unsigned long long myev = KMC_XP_NOEV;
             double ev_before = 0.0, ev_after = 0.0, ev_p = 0.0;
             const bool look = flag || (c > 0.0 && (base + run >= two53 || ldexp((double)(base + run), ex - 52) >= cstar));
@@ -427,7 +430,7 @@ restart:
                 }
             }
             if (myev != KMC_XP_NOEV) atomicMin(&sh->ev, myev);
-            __syncthreads();
+            XP_SYNC();
             const unsigned long long ev = sh->ev;
             if (ev != KMC_XP_NOEV && ev == myev) {
                 const long k = (long)(ev >> 1);
@@ -439,17 +442,17 @@ restart:
                     else { sh->c = cn; sh->pos = k + 1; }
                 }
             }
-            __syncthreads();
+            XP_SYNC();
             if (ev == KMC_XP_NOEV) { c = c_end; pos = tile_end; }
             else { c = sh->c; pos = sh->pos; done = sh->done != 0; }
         }
     }
-    __syncthreads();
+    XP_SYNC();
     if (fast) {
         // the short form stands if an entry reached T_hi and the one before it is below T_lo
         if (tid == 0) sh->done = (sh->idx < n6 && sh->cprev_found < t_lo) ? 1 : 3;
-        __syncthreads();
-        if (sh->done == 3) { __syncthreads(); fast = false; total = 0.0; goto restart; }
+        XP_SYNC();
+        if (sh->done == 3) { XP_SYNC(); fast = false; total = 0.0; goto restart; }
     }
     XP_TRACE(6, __builtin_amdgcn_s_memtime() - xp_t0);
 }

@@ -27,7 +27,8 @@ using namespace kmc;
 
 #define KMC_TABLE_ROWS (1u << 18)
 #define KMC_EV_RING 64
-#define KMC_LAT_AUTO_MAX 256      // hop_lat_kernel is the default up to one replica per CU
+#define KMC_LAT_ONE_PER_CU 256    // hop_lat_kernel: one replica per CU up to here, two (its PK layout) beyond
+#define KMC_LAT_AUTO_MAX 512      // hop_lat_kernel is the default up to two replicas per CU
 
 // ======================================================================
 // context
@@ -45,7 +46,7 @@ struct kmc_ctx {
     // (taken when the replicas fit one per CU and the table's distinct rates fit the palette), 1 = forced
     // (kmc_set_hop_kernel(ctx, 5)), -1 = never.  pal_state: 0 = palette not built for the current table, 1 = built,
     // -1 = the table holds more than LAT_PAL_MAX distinct rates.
-    bool lat_ok; int lat_mode, pal_state, n_pal;
+    bool lat_ok, lat_pk; int lat_mode, pal_state, n_pal;
     LatWP* wp;             // [2^18] {W, palette indices} (lazy)
     double* pal;           // [LAT_PAL_MAX]
     bool big_ok, use_big;  // larger lattices whose bitmaps fit LDS: kmc_hop_big.h (else kmc_hop_global.h)
@@ -760,9 +761,12 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     if (c->lds64 || c->qany_ok) CREATE_CHK(hipMalloc(&c->xscratch, (size_t)c->R * Q64_XSCRATCH));
     c->lat_ok = c->lds64 || c->qany_ok;
     if (c->lat_ok) {
-        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_LDS_BYTES));
-        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_LDS_BYTES));
-        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_LDS_BYTES));
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_LDS_BYTES));
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_LDS_BYTES));
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_LDS_BYTES));
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT2_LDS_BYTES));
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT2_LDS_BYTES));
+        CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT2_LDS_BYTES));
     }
     if (c->lds_path) {
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lds64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, K64_LDS_BYTES));
@@ -903,11 +907,12 @@ int kmc_lds_bytes(kmc_ctx* c)
 int kmc_set_hop_kernel(kmc_ctx* c, int which)
 {
     CTXCHK(c);
-    if (which < 0 || which > 5) return fail(c, KMC_EINVAL, "kmc_set_hop_kernel: which must be 0 ... 5");
-    if (which == 5 && !c->lat_ok)
+    if (which < 0 || which > 6) return fail(c, KMC_EINVAL, "kmc_set_hop_kernel: which must be 0 ... 6");
+    if (which >= 5 && !c->lat_ok)
         return fail(c, KMC_EINVAL, "kmc_set_hop_kernel: the one-replica-per-CU kernel takes lattices of 8 ... 64 rows and columns");
-    c->lat_mode = which == 5 ? 1 : (which == 0 ? 0 : -1);
-    if (which == 5) which = 0;
+    c->lat_mode = which >= 5 ? 1 : (which == 0 ? 0 : -1);
+    c->lat_pk = which == 6;                    // its two-per-CU layout whatever the replica count (tests)
+    if (which >= 5) which = 0;
     c->lds64 = c->lds_path && c->nx == 64 && c->ny == 64 && which != 1 && which != 4;
     c->qany = c->qany_ok && (which == 4 || which == 0);
     c->q64 = c->lds64 && (which == 3 || (which == 0 && c->q64_auto));
@@ -920,7 +925,8 @@ const char* kmc_hop_kernel_name(kmc_ctx* c)
     if (!c) return "none";
     if (!c->lds_path) return c->use_big ? "hop_big_kernel" : "hop_global_kernel";
     if (c->lat_ok && c->pal_state >= 0 && (c->lat_mode == 1 || (c->lat_mode == 0 && c->R <= KMC_LAT_AUTO_MAX && c->split != 2)))
-        return c->lds64 ? "hop_lat_kernel" : "hop_lat_kernel<any>";
+        return c->R > KMC_LAT_ONE_PER_CU || c->lat_pk ? (c->lds64 ? "hop_lat_kernel<2 per CU>" : "hop_lat_kernel<any, 2 per CU>")
+                                         : (c->lds64 ? "hop_lat_kernel" : "hop_lat_kernel<any>");
     if (c->qany) return "hop_q64_kernel<any>";
     if (c->lds64) return c->q64 ? "hop_q64_kernel" : "hop_lds64_kernel";
     return "hop_lds_kernel";
@@ -1445,9 +1451,19 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         c->run_groups[slot] = 1;
         time_begin(c);
         HIPCHK(c, hipEventRecord(c->run_ev[slot][0][0], c->stream));
-        if (c->lds64) hop_lat_kernel<false, true><<<c->R, 64, LAT_LDS_BYTES, c->stream>>>(lp);
-        else if (lat_cls_ok(c->ny, c->window_mode)) hop_lat_kernel<true, true><<<c->R, 64, LAT_LDS_BYTES, c->stream>>>(lp);
-        else hop_lat_kernel<true, false><<<c->R, 64, LAT_LDS_BYTES, c->stream>>>(lp);
+        lp.n_rep = c->R;
+        const bool cls = lat_cls_ok(c->ny, c->window_mode);
+        if (c->R > KMC_LAT_ONE_PER_CU || c->lat_pk) {
+            // more replicas than CUs: two to a CU, one 2-wave workgroup each (kmc_hop_lat.h, PK)
+            const int nb = (c->R + 1) / 2;
+            if (c->lds64) hop_lat_kernel<false, true, true><<<nb, 128, LAT2_LDS_BYTES, c->stream>>>(lp);
+            else if (cls) hop_lat_kernel<true, true, true><<<nb, 128, LAT2_LDS_BYTES, c->stream>>>(lp);
+            else hop_lat_kernel<true, false, true><<<nb, 128, LAT2_LDS_BYTES, c->stream>>>(lp);
+        } else {
+            if (c->lds64) hop_lat_kernel<false, true, false><<<c->R, 64, LAT_LDS_BYTES, c->stream>>>(lp);
+            else if (cls) hop_lat_kernel<true, true, false><<<c->R, 64, LAT_LDS_BYTES, c->stream>>>(lp);
+            else hop_lat_kernel<true, false, false><<<c->R, 64, LAT_LDS_BYTES, c->stream>>>(lp);
+        }
         HIPCHK(c, hipEventRecord(c->run_ev[slot][0][1], c->stream));
         time_end(c);
         ++c->run_launches;

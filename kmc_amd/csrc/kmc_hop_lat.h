@@ -32,6 +32,7 @@
 
 namespace kmc {
 
+#define LAT_PAL_MAX 1024
 #define LAT_STRIDE 72
 // FR, ST and PAL first: every address the hop loop computes in a register then takes its array's base as the 16-bit
 // immediate offset of the LDS instruction
@@ -42,11 +43,26 @@ namespace kmc {
 #define LAT_MISC (LAT_WR + 64 * LAT_STRIDE * 16)
 #define LAT_IDLE (LAT_MISC + 96)                       // u32 [64]: where the idle lanes of the fresh-key atomics point
 #define LAT_LDS_BYTES (LAT_IDLE + 256)
-#define LAT_PAL_MAX 1024
 #define LAT_OCC_BIT 0x40000u
 
 static_assert(LAT_LDS_BYTES <= 160 * 1024, "one replica per CU");
 static_assert(LAT_WR + 8 < 65536, "immediate offsets of the LDS instructions");
+
+// PK (two replicas per CU, for 257 ... 512 replicas per GPU): one 128-thread workgroup = two waves = two replicas that share
+// the palette; each wave's planes are squeezed to 76 KB: row stride 64, the fresh keys as a u16 plane (key bits 0-15) and
+// a 4-bit plane (key bits 16, 17 and the occupancy bit; eight sites per dword, the LDS atomics take any bit of a dword),
+// and the stale keys not in LDS at all -- a refreshed site's key is stored straight to the replica's key array in global
+// memory (one store per hop, issued behind the gather so that the wait for the gather does not wait for it).
+#define LAT2_STRIDE 64
+#define LAT2_PAL 0
+#define LAT2_REGION0 (LAT_PAL_MAX * 8)
+#define LAT2_A16 0
+#define LAT2_B4 8192
+#define LAT2_MISC (LAT2_B4 + 2048)
+#define LAT2_IDLE (LAT2_MISC + 96)
+#define LAT2_WR (LAT2_IDLE + 256)
+#define LAT2_REGION (LAT2_WR + 64 * LAT2_STRIDE * 16)
+#define LAT2_LDS_BYTES (LAT2_REGION0 + 2 * LAT2_REGION)
 
 struct __attribute__((aligned(16))) LatWP {
     double w;                    // row_sum6 of the table row
@@ -57,7 +73,9 @@ struct LatParams {
     HopParams h;
     const LatWP* wp;             // [2^18]
     const double* pal;           // [LAT_PAL_MAX], pal[0] = 0.0
+    int n_rep;                   // replicas of this launch (PK: two per workgroup, the last one may hold one)
 };
+static_assert(LAT2_WR % 16 == 0 && LAT2_REGION % 16 == 0 && LAT2_LDS_BYTES <= 160 * 1024, "two replicas per CU");
 
 __device__ __noinline__ void exact_select_lat(const unsigned char* smem, const double* table, int ny, int n, double rho,
                                               ExactParShared* sh)
@@ -66,6 +84,15 @@ __device__ __noinline__ void exact_select_lat(const unsigned char* smem, const d
     exact_select_par_impl<1, 2, true>([=](long s) -> uint32_t {
         const int i = (int)s / ny, j = (int)s - i * ny;
         return st[i * LAT_STRIDE + j];
+    }, table, n, rho, sh);
+}
+
+// PK: the stale keys live in the replica's key array in global memory, where the hop loop stores them as it refreshes
+// sites; read past the vector L1 (agent scope), which the wave's own stores do not update.
+__device__ __noinline__ void exact_select_lat_g(const uint32_t* keys, const double* table, int n, double rho, ExactParShared* sh)
+{
+    exact_select_par_impl<1, 2, true>([=](long s) -> uint32_t {
+        return __hip_atomic_load(keys + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }, table, n, rho, sh);
 }
 
@@ -90,39 +117,68 @@ __host__ __device__ inline bool lat_cls_ok(int ny, int window_mode)
     return m == 0 || m >= widest;
 }
 
-template <bool ANY, bool CLS>
-__global__ __launch_bounds__(64)
+template <bool ANY, bool CLS, bool PK>
+__global__ __launch_bounds__(PK ? 128 : 64)
 void hop_lat_kernel(LatParams lp)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const HopParams& p = lp.h;
-    const int r = p.order ? p.order[blockIdx.x + p.r_base] : (int)blockIdx.x + p.r_base, lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    // (the wave's number as a scalar: to the compiler threadIdx.x >> 6 is a per-lane value, and with it every loop bound below)
+    const int wave = PK ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int slot = PK ? (int)blockIdx.x * 2 + wave : (int)blockIdx.x;     // replica slot of this wave
+    constexpr int S = PK ? LAT2_STRIDE : LAT_STRIDE;   // row stride of the planes, in sites
+    double* PAL_l = reinterpret_cast<double*>(smem_all + (PK ? LAT2_PAL : LAT_PAL));
+    if (PK) {
+        // the palette is the one thing the two waves share: filled by both, then each wave is on its own (no barrier after)
+        for (int k = threadIdx.x; k < LAT_PAL_MAX; k += 128) PAL_l[k] = lp.pal[k];
+        __syncthreads();
+        if (slot >= lp.n_rep) return;
+    }
+    unsigned char* const smem = smem_all + (PK ? LAT2_REGION0 + wave * LAT2_REGION : 0);
+    const int r = p.order ? p.order[slot + p.r_base] : slot + p.r_base;
     const int nx = ANY ? p.nx : 64, ny = ANY ? p.ny : 64;
     const int n = ANY ? p.n : 4096;
-    LatWP* WR_l = reinterpret_cast<LatWP*>(smem + LAT_WR);
-    uint32_t* FR_l = reinterpret_cast<uint32_t*>(smem + LAT_FR);
-    uint32_t* ST_l = reinterpret_cast<uint32_t*>(smem + LAT_ST);
-    double* PAL_l = reinterpret_cast<double*>(smem + LAT_PAL);
+    LatWP* WR_l = reinterpret_cast<LatWP*>(smem + (PK ? LAT2_WR : LAT_WR));
+    uint32_t* FR_l = reinterpret_cast<uint32_t*>(smem + (PK ? LAT2_A16 : LAT_FR));    // PK: two u16 per dword
+    uint32_t* FB_l = reinterpret_cast<uint32_t*>(smem + LAT2_B4);                      // PK only: eight nibbles per dword
+    uint32_t* ST_l = reinterpret_cast<uint32_t*>(smem + LAT_ST);                       // not PK only
+    // the 19-bit fresh word of site s (key | occupancy << 18), and the dword / bit a key bit lives at
+    auto fr_word = [&](int s) -> uint32_t {
+        if (!PK) return FR_l[s];
+        const uint32_t a = reinterpret_cast<const uint16_t*>(FR_l)[s];
+        return a | (((FB_l[s >> 3] >> ((s & 7) * 4)) & 7u) << 16);
+    };
+    auto fr_or = [&](int s, int bit) {                 // prologue: set bit `bit` (0 .. 18) of site s
+        if (!PK) atomicOr(&FR_l[s], 1u << bit);
+        else if (bit < 16) atomicOr(&FR_l[s >> 1], 1u << ((s & 1) * 16 + bit));
+        else atomicOr(&FB_l[s >> 3], 1u << ((s & 7) * 4 + (bit - 16)));
+    };
     ExactParShared* const xsh = reinterpret_cast<ExactParShared*>(reinterpret_cast<unsigned char*>(p.xscratch) + (size_t)r * Q64_XSCRATCH);
     uint8_t* const occ_g = p.occ + (size_t)r * n;
     uint32_t* const keys_g = p.keys + (size_t)r * n;
     int4* const tags_g = p.tags + (size_t)r * n;
-    auto ext = [&](int so) -> int { const int i = so / LAT_STRIDE, j = so - i * LAT_STRIDE; return i * ny + j; };
+    auto ext = [&](int so) -> int { const int i = so / S, j = so - i * S; return i * ny + j; };
     auto wrap_i = [&](int a) -> int { return ANY ? (a < 0 ? a + nx : (a >= nx ? a - nx : a)) : (a & 63); };
     auto wrap_j = [&](int a) -> int { return ANY ? (a < 0 ? a + ny : (a >= ny ? a - ny : a)) : (a & 63); };
 
     // ---- load the replica ------------------------------------------------
-    for (int k = lane; k < LAT_PAL_MAX; k += KMC_WAVE) PAL_l[k] = lp.pal[k];
-    for (int k = lane; k < 64 * LAT_STRIDE; k += KMC_WAVE) { FR_l[k] = 0u; ST_l[k] = Q64_VAC; WR_l[k].w = 0.0; WR_l[k].rp = 0ull; }
+    if (!PK) {
+        for (int k = lane; k < LAT_PAL_MAX; k += KMC_WAVE) PAL_l[k] = lp.pal[k];
+        for (int k = lane; k < 64 * S; k += KMC_WAVE) { FR_l[k] = 0u; ST_l[k] = Q64_VAC; }
+    } else {
+        for (int k = lane; k < (8192 + 2048) / 4; k += KMC_WAVE) FR_l[k] = 0u;          // both fresh-key planes
+    }
+    for (int k = lane; k < 64 * S; k += KMC_WAVE) { WR_l[k].w = 0.0; WR_l[k].rp = 0ull; }
     wave_fence();
     // fresh keys: every occupied site sets its bit in the 18 sites that see it, and its own occupancy bit
     if (!ANY || lane < ny) {
         for (int i = 0; i < nx; ++i) {
             if (occ_g[i * ny + lane] & 1u) {
-                atomicOr(&FR_l[i * LAT_STRIDE + lane], LAT_OCC_BIT);
+                fr_or(i * S + lane, 18);
 #pragma unroll
                 for (int q = 0; q < 18; ++q)
-                    atomicOr(&FR_l[wrap_i(i - kNbI[q]) * LAT_STRIDE + wrap_j(lane - kNbJ[q])], 1u << (17 - q));
+                    fr_or(wrap_i(i - kNbI[q]) * S + wrap_j(lane - kNbJ[q]), 17 - q);
             }
         }
     }
@@ -142,8 +198,8 @@ void hop_lat_kernel(LatParams lp)
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 if (i0 + q < nx) {
-                    const int so = (i0 + q) * LAT_STRIDE + lane;
-                    ST_l[so] = k[q];
+                    const int so = (i0 + q) * S + lane;
+                    if (!PK) ST_l[so] = k[q];
                     WR_l[so] = v[q];
                 }
             }
@@ -155,7 +211,7 @@ void hop_lat_kernel(LatParams lp)
     // the sum of row `row` (all 8 lanes of group a receive it): leaves c, c + 8, ... c + 56 per lane as a balanced
     // tree, then the 8-lane tree (group8_sum).  A pure function of the row's W with one fixed association.
     auto row_tree = [&](int row) -> double {
-        const LatWP* w = WR_l + row * LAT_STRIDE + grp_c;
+        const LatWP* w = WR_l + row * S + grp_c;
         const double l0 = w[0].w, l1 = w[8].w, l2 = w[16].w, l3 = w[24].w, l4 = w[32].w, l5 = w[40].w, l6 = w[48].w, l7 = w[56].w;
         return group8_sum(((l0 + l1) + (l2 + l3)) + ((l4 + l5) + (l6 + l7)));
     };
@@ -174,9 +230,9 @@ void hop_lat_kernel(LatParams lp)
 
     int status = 0;
     long long n_exact = 0, hops = 0;
-    long long* hist_l = reinterpret_cast<long long*>(smem + LAT_MISC);            // [6]
-    double* time_l = reinterpret_cast<double*>(smem + LAT_MISC + 48);              // launch clock
-    double* bstat_l = reinterpret_cast<double*>(smem + LAT_MISC + 56);             // last, sum, min, max, count
+    long long* hist_l = reinterpret_cast<long long*>(smem + (PK ? LAT2_MISC : LAT_MISC));            // [6]
+    double* time_l = reinterpret_cast<double*>(smem + (PK ? LAT2_MISC : LAT_MISC) + 48);              // launch clock
+    double* bstat_l = reinterpret_cast<double*>(smem + (PK ? LAT2_MISC : LAT_MISC) + 56);             // last, sum, min, max, count
     if (lane < 6) hist_l[lane] = 0;
     if (lane == 0) time_l[0] = 0.0;
     if (lane < 5) bstat_l[lane] = lane == 0 ? p.barrier[r * 5 + 0] : (lane == 2 ? 1e300 : (lane == 3 ? -1e300 : 0.0));
@@ -195,9 +251,16 @@ void hop_lat_kernel(LatParams lp)
     const int at_dj = at_on && at_q < 18 ? -kNbJ[at_q < 18 ? at_q : 0] : 0;
     const uint32_t at_bit = at_on ? (at_q < 18 ? 1u << (17 - at_q) : LAT_OCC_BIT) : 0u;
     const int at_end = lane >= 32 ? -1 : 0;            // all ones: this lane works on the end point
-    uint32_t* const at_idle = reinterpret_cast<uint32_t*>(smem + LAT_IDLE) + lane;
+    uint32_t* const at_idle = reinterpret_cast<uint32_t*>(smem + (PK ? LAT2_IDLE : LAT_IDLE)) + lane;
     const uint32_t at_and = (lane < 32) ? ~at_bit : ~0u;
     const uint32_t at_or = (lane >= 32) ? at_bit : 0u;
+    // PK: this lane's key bit lives in the u16 plane (bits 0-15: dword s >> 1, shift 16 (s & 1) + bit) or in the nibble
+    // plane (bits 16-18: dword s >> 3, shift 4 (s & 7) + bit - 16): which one is a constant of the lane
+    const int at_b = at_on ? (at_q < 18 ? 17 - at_q : 18) : 0;
+    const bool at_hi = at_b >= 16;
+    const uint32_t pk_dsh = at_hi ? 3u : 1u, pk_m = at_hi ? 7u : 1u, pk_k = at_hi ? 2u : 4u, pk_pb = at_hi ? (uint32_t)at_b - 16u : (uint32_t)at_b;
+    uint32_t* const pk_base = at_hi ? FB_l : FR_l;
+    const uint32_t pk_src = (at_on && lane < 32) ? ~0u : 0u, pk_dst = (at_on && lane >= 32) ? ~0u : 0u;
     const uint32_t rp_sh = lane < 6 ? 10u * (uint32_t)lane : 60u;       // lanes >= 6 read index 0 (rate 0)
     // the geometry of a hop in direction d (:503-504) and of its refresh window (:444-453; the three window modes as in
     // the other kernels: i_lo = i - 2 + ext * min(di, 0), n_i = ni0 + ext * |di|), packed in lane d: one lane read and
@@ -253,7 +316,12 @@ void hop_lat_kernel(LatParams lp)
             // ---- exact path (rare): the reference's selection replayed literally for hop h0 -----
             need_exact = false;
             wave_fence();
-            exact_select_lat(smem, p.table, ny, n, readlane_f64(rho_v, 0), xsh);
+            if (PK) {
+                __threadfence();                // the key stores of the hops so far have reached the L2
+                exact_select_lat_g(keys_g, p.table, n, readlane_f64(rho_v, 0), xsh);
+            } else {
+                exact_select_lat(smem, p.table, ny, n, readlane_f64(rho_v, 0), xsh);
+            }
             wave_fence();
             ++n_exact;
             if (!(xsh->gamma > 0.0)) { status = 2; run = 0; }
@@ -277,7 +345,7 @@ void hop_lat_kernel(LatParams lp)
             const int i = ff1_63(ballot64(rowpre >= t));
             const double base_i = readlane_f64(rowex, i);
             // ---- site: the row's 64 W (and palette words, used after the pick), one scan -----------
-            const LatWP wr_row = WR_l[i * LAT_STRIDE + lane];
+            const LatWP wr_row = WR_l[i * S + lane];
             const double wv = wr_row.w;
             const unsigned long long rp_row = wr_row.rp;
             const double wsc = wave_scan_incl_z(wv, sz);
@@ -326,16 +394,24 @@ void hop_lat_kernel(LatParams lp)
             const int n_i = (int)__builtin_amdgcn_ubfe((uint32_t)gw, 10, 3), n_j = (int)__builtin_amdgcn_ubfe((uint32_t)gw, 13, 3);
             const int ie = ii + di, je = j + dj;                 // unwrapped
             const int iw = wrap_i(ie), jw = wrap_j(je);
-            const int s_src = ii * LAT_STRIDE + j, s_dst = iw * LAT_STRIDE + jw;
+            const int s_src = ii * S + j, s_dst = iw * S + jw;
             // fresh keys: clear the start point's bit in the sites that see it, set the end point's (AND / OR, not
             // flips: with rho == 0 the reference "hops" entry 0 whatever its rate, B4)
             {
                 const int ti = wrap_i(ii + at_di + (di & at_end));
                 const int tj = wrap_j(j + at_dj + (dj & at_end));
                 // (idle lanes AND ~0 / OR 0 into a word of their own: thirteen lanes on ONE address would be serialised)
-                uint32_t* fa = at_on ? FR_l + (ti * LAT_STRIDE + tj) : at_idle;
-                __hip_atomic_fetch_and(fa, at_and, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_or(fa, at_or, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (!PK) {
+                    uint32_t* fa = at_on ? FR_l + (ti * S + tj) : at_idle;
+                    __hip_atomic_fetch_and(fa, at_and, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_or(fa, at_or, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                } else {
+                    const uint32_t ts = (uint32_t)(ti * S + tj);
+                    uint32_t* fa = at_on ? pk_base + (ts >> pk_dsh) : at_idle;
+                    const uint32_t mk = 1u << (((ts & pk_m) << pk_k) + pk_pb);
+                    __hip_atomic_fetch_and(fa, ~(mk & pk_src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_or(fa, mk & pk_dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
             }
             // ---- windowed refresh (:444-465): lane (a, c) = window row a and the window column = c (mod 8), so that
             // the lane's site is a leaf of ITS class in the row's tree (columns c, c + 8, ... c + 56).  That needs the
@@ -364,22 +440,25 @@ void hop_lat_kernel(LatParams lp)
                 sj = j_lo0 + grp_c; sj = sj >= ny ? sj - ny : sj;
                 inw &= grp_c < n_j;
             }
-            const int srow = si * LAT_STRIDE;
+            const int srow = si * S;
             const int so = srow + sj;
             wave_fence();
-            uint32_t knew = FR_l[so];
+            uint32_t knew = fr_word(so);
+            uint32_t kglob;                      // what the key array in global memory holds for the site: 0xFFFFFFFF if vacant
             {
                 // vacant site -> 0x3FFFF: the sign-extended occupancy bit selects (no compare, no VCC)
                 const uint32_t om = (uint32_t)__builtin_amdgcn_sbfe((int)knew, 18u, 1u);
-                knew = ((knew & om) | ~om) & 0x3FFFFu;
+                kglob = (knew & 0x3FFFFu) | ~om;
+                knew = kglob & 0x3FFFFu;
             }
             LatWP wn;
             asm("" : "=v"(wn.w), "=v"(wn.rp));
             if (inw) {
-                ST_l[so] = knew;
+                if (!PK) ST_l[so] = knew;
                 uint32_t ko = knew << 4;
                 asm("" : "+v"(ko));              // one 32-bit value: an SGPR base + VGPR offset load
                 wn = *reinterpret_cast<const LatWP*>(wp_b + ko);
+                if (PK) keys_g[ANY ? si * ny + sj : so] = kglob;      // behind the gather: its wait leaves this store in flight
             }
             // ---- while the gather is in flight: what nothing in this hop waits for, and the unchanged part of the
             // window rows' sums.  A row's sum is the balanced tree over its 64 W; the lane's own leaf (column oc, the
@@ -455,7 +534,7 @@ void hop_lat_kernel(LatParams lp)
             int4 tv = make_int4(0, 0, 0, 0);
             if (used) tv = tags_g[ext(tg_vac)];
             // the site an atom left is vacant now unless a moved atom sits on it, i.e. unless it is occupied
-            const bool home_empty = used && (FR_l[used ? tg_vac : 0] & LAT_OCC_BIT) == 0u;
+            const bool home_empty = used && (fr_word(used ? tg_vac : 0) & LAT_OCC_BIT) == 0u;
             tv.z += ((tg_ow >> 8) & 255) - 64;
             tv.w += ((tg_ow >> 16) & 255) - 64;
             if (used) tags_g[ext(tg_site)] = tv;
@@ -498,10 +577,10 @@ void hop_lat_kernel(LatParams lp)
     wave_fence();
     if (!ANY || lane < ny) {
         for (int i = 0; i < nx; ++i) {
-            const uint32_t f = FR_l[i * LAT_STRIDE + lane];
+            const uint32_t f = fr_word(i * S + lane);
             const bool o = (f & LAT_OCC_BIT) != 0u;
             occ_g[i * ny + lane] = (uint8_t)o;
-            keys_g[i * ny + lane] = o ? ST_l[i * LAT_STRIDE + lane] : KMC_VACANT;
+            if (!PK) keys_g[i * ny + lane] = o ? ST_l[i * S + lane] : KMC_VACANT;      // (PK: stored as the sites were refreshed)
         }
     }
     if (lane < 6) p.hist[r * 6 + lane] += hist_l[lane];

@@ -86,6 +86,8 @@ CASES = [
     (64, 64, 'normcons', 5, 240, 480),
     (64, 64, 'master', 5, 240, 480),
     (30, 30, 'master', 5, 240, 480),
+    (64, 64, 'master', 6, 240, 480),
+    (30, 30, 'normcons', 6, 240, 480),
     (64, 64, 'normcons', 3, 240, 480),
     (64, 64, 'master', 3, 240, 480),
     (64, 64, 'normcons', 2, 120, 240),
@@ -100,7 +102,7 @@ CASES = [
     (300, 260, 'master', 0, 36, 72),
     (300, 260, 'master', 1, 18, 36),
 ]
-KERNEL_NAMES = {(64, 5): 'lat', (30, 5): 'lat', (64, 3): 'q64', (64, 2): 'lds64', (64, 1): 'generic', (30, 4): 'qany', (30, 1): 'generic',
+KERNEL_NAMES = {(64, 5): 'lat', (30, 5): 'lat', (64, 6): 'lat2', (30, 6): 'lat2', (64, 3): 'q64', (64, 2): 'lds64', (64, 1): 'generic', (30, 4): 'qany', (30, 1): 'generic',
                 (70, 0): 'big', (70, 1): 'global', (300, 0): 'big', (300, 1): 'global'}
 
 
@@ -149,7 +151,7 @@ def test_draw_above_the_cdf(kmc, base_tables, dense_tables):
     """B4 on the master fold: rho one ulp above cdf[-1] is the reference's IndexError: the replica stops with status 1 at
     that hop, every kernel family.  (rho == 0: tests/test_gpu_parity.py::test_selection_edges.)"""
     dense = dense_tables['master']
-    for (nx, ny, which) in [(64, 64, 5), (30, 30, 5), (64, 64, 3), (30, 30, 4), (30, 30, 1), (70, 66, 0), (70, 66, 1)]:
+    for (nx, ny, which) in [(64, 64, 5), (30, 30, 5), (64, 64, 6), (64, 64, 3), (30, 30, 4), (30, 30, 1), (70, 66, 0), (70, 66, 1)]:
         rs = np.random.RandomState(nx + which)
         occ = (rs.rand(nx, ny) < 0.5).astype(np.int8)
         rep = CO.Replica(occ, dense)

@@ -203,10 +203,11 @@ def test_golden_trajectory(kmc, tables, dense, dense_master, path, force_exact):
 @pytest.mark.parametrize('name,which', [('n64_x05', 1), ('n64_x05', 2), ('n64_x05', 3), ('n30_x05_master', 1), ('n30_x05_master', 4),
                                         ('n30_x05', 1), ('n30_x05', 4), ('n8x12_x05', 4),
                                         ('n70x66_x04_master', 0), ('n70x66_x04_master', 1),
-                                        ('n64_x05', 5), ('n30_x05_master', 5), ('n30_x05', 5), ('n8x12_x05', 5), ('n10_x03_master', 5)],
+                                        ('n64_x05', 5), ('n30_x05_master', 5), ('n30_x05', 5), ('n8x12_x05', 5), ('n10_x03_master', 5),
+                                        ('n64_x05', 6), ('n30_x05_master', 6), ('n8x12_x05', 6)],
                          ids=['n64-generic', 'n64-lds64', 'n64-q64', 'n30master-generic', 'n30master-q', 'n30-generic', 'n30-q', 'n8x12-q',
                               'n70x66master-big', 'n70x66master-global', 'n64-lat', 'n30master-lat', 'n30-lat', 'n8x12-lat',
-                              'n10master-lat'])
+                              'n10master-lat', 'n64-lat2', 'n30master-lat2', 'n8x12-lat2'])
 def test_reference_trajectory_every_kernel_family(kmc, tables, dense, dense_master, name, which, force_exact):
     """The reference-generated trajectories at BASELINE's lattice sizes through EVERY hop kernel that can take them
     (kmc_set_hop_kernel), certified and with every hop forced through the exact replay: selections, lattice, tags,
@@ -280,7 +281,7 @@ def test_random_ensemble_vs_oracle(kmc, tables, dense, cfg):
     # 64 x 64 has two kernels (16 replicas per CU, the default, and 8): both; 8 ... 64 rows and columns: the 16-per-CU
     # layout (the default) and the any-size kernel with block sums in LDS
     # (5: the one-replica-per-CU kernel, kmc_hop_lat.h -- what a context of up to 256 replicas takes by default)
-    for which in ((3, 2, 5) if (nx, ny) == (64, 64) else ((4, 1, 5) if min(nx, ny) >= 8 else (0,))):
+    for which in ((3, 2, 5, 6) if (nx, ny) == (64, 64) else ((4, 1, 5, 6) if min(nx, ny) >= 8 else (0,))):
         _ensemble_vs_oracle(kmc, tables, cfg, which, occ, d_pre, d_sim, oracle)
 
 
@@ -330,7 +331,7 @@ def test_lds64_kernel_equals_generic_kernel(kmc, tables, mode):
     R, hp, hs, seed = 72, 4096 + 37, 10000, 0xC0FFEE
     conc = np.repeat(np.linspace(0.1, 0.9, 9), 8)
     out = []
-    for which in (3, 2, 1, 5):                   # q64, lds64, generic, one-per-CU
+    for which in (3, 2, 1, 5, 6):                # q64, lds64, generic, one-per-CU, two-per-CU
         with make_engine(kmc, tables, R, 64, 64, mode) as eng:
             eng.set_hop_kernel(which=which)
             eng.fill_random(conc, 99)
@@ -344,8 +345,10 @@ def test_lds64_kernel_equals_generic_kernel(kmc, tables, mode):
             out.append((i1, i2, i3, eng.get_lattice(), eng.get_keys(), eng.get_displacements(), sc['hist'], st['status'],
                         sc['time'], sc['step_time'], sc['gamma'], st['n_exact'],
                         np.stack(list(eng.barrier_stats().values()))))
-    q64, lds64, generic, lat = out
+    q64, lds64, generic, lat, lat2 = out
     for a, b in zip(lds64, generic):
+        assert np.array_equal(a, b)
+    for a, b in zip(lat2, lat):                      # the two layouts of one kernel: the same sums, bit for bit
         assert np.array_equal(a, b)
     for other in (q64, lat):
         for k in range(8):                           # integer state: exact
@@ -465,8 +468,8 @@ def test_philox_stream_run_matches_injected(kmc, tables, dense):
 
 
 # ---------------------------------------------------------------- edges
-@pytest.mark.parametrize('nx,ny,which', [(10, 10, 0), (64, 64, 3), (64, 64, 2), (70, 66, 0), (64, 64, 5), (10, 10, 4), (7, 9, 0)],
-                         ids=['lat-10x10', 'q64', 'lds64', 'big-70x66', 'lat', 'q-10x10', 'lds-7x9'])
+@pytest.mark.parametrize('nx,ny,which', [(10, 10, 0), (64, 64, 3), (64, 64, 2), (70, 66, 0), (64, 64, 5), (10, 10, 4), (7, 9, 0), (64, 64, 6), (10, 10, 6)],
+                         ids=['lat-10x10', 'q64', 'lds64', 'big-70x66', 'lat', 'q-10x10', 'lds-7x9', 'lat2', 'lat2-10x10'])
 def test_selection_edges(kmc, tables, dense, nx, ny, which):
     """rho == 0 picks index 0 (searchsorted left); rho above cumsum[-1]/gamma is the
     reference's IndexError -> the replica stops with KMC_ST_OVERFLOW; a lattice
