@@ -284,6 +284,10 @@ void hop_lat_kernel(LatParams lp)
     const long long my_hops = p.n_hops_r ? p.n_hops_r[r] : p.n_hops;
     const unsigned char* __restrict__ wp_b = reinterpret_cast<const unsigned char*>(lp.wp);
 
+#ifdef KMC_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
     bool need_exact = false;
     int done = 0;
     for (long long h0 = 0; h0 < my_hops && status == 0; h0 += done) {
@@ -331,6 +335,7 @@ void hop_lat_kernel(LatParams lp)
                 if (xsh->idx == 0) run = 1;     // rho <= 0 selects entry 0 whatever its rate (B4): a chunk of its own
             }
         }
+        KMC_STAMP(0);
         for (; hl < run; ++hl) {
             const double t = readlane_f64(rho_v * gamma, hl);
             if (__double2hiint(gamma) >= m_hi_limit) {
@@ -351,6 +356,7 @@ void hop_lat_kernel(LatParams lp)
             const double wsc = wave_scan_incl_z(wv, sz);
             const int js = ff1_63(ballot64(base_i + wsc >= t));       // no site reaches t: 63, and nothing certifies
             const double lo_site = readlane_f64(base_i + dpp_f64<0x138, 0xF>(wsc), js);
+            KMC_STAMP(1);
             // ---- direction: the site's six palette entries on lanes 0..5 -------------
             const uint32_t rp_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rp_row, js);
             const uint32_t rp_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rp_row >> 32), js);
@@ -360,6 +366,7 @@ void hop_lat_kernel(LatParams lp)
             double rs = rate + dpp_f64<0x111, 0xF>(rate);
             rs += dpp_f64<0x112, 0xF>(rs);
             rs += dpp_f64<0x114, 0xF>(rs);
+            KMC_STAMP(7);
             const double ap = lo_site + rs;
             const double ape = lo_site + dpp_f64<0x111, 0xF>(rs);
             const unsigned long long md = ballot64(ap >= t) & 0x3Full;
@@ -385,6 +392,7 @@ void hop_lat_kernel(LatParams lp)
                 pnum_hi = __builtin_amdgcn_readfirstlane(__double2hiint(pn));
                 exact_flag = 1 << 30;
             }
+            KMC_STAMP(2);
             const int ii = i_sel;
             const int idx = (ii * ny + j) * 6 + d;
             // ---- update (:518-535): the hop's geometry, packed per direction in lane d of `geo` ---------
@@ -460,6 +468,7 @@ void hop_lat_kernel(LatParams lp)
                 wn = *reinterpret_cast<const LatWP*>(wp_b + ko);
                 if (PK) keys_g[ANY ? si * ny + sj : so] = kglob;      // behind the gather: its wait leaves this store in flight
             }
+            KMC_STAMP(3);
             // ---- while the gather is in flight: what nothing in this hop waits for, and the unchanged part of the
             // window rows' sums.  A row's sum is the balanced tree over its 64 W; the lane's own leaf (column oc, the
             // refreshed site or, for lanes without one, column c) meets its sibling leaf, then the sibling pair, then
@@ -488,6 +497,7 @@ void hop_lat_kernel(LatParams lp)
                 const int now_ = (seen ? oow : (64 << 8) + (64 << 16)) + wrap;
                 writelane2(tg_sv, tg_ow, nsv, now_, lm);
             }
+            KMC_STAMP(4);
             // ---- re-sum the window's rows, re-scan ------------------------------------------------
             double s;
             if (classes) {
@@ -509,10 +519,12 @@ void hop_lat_kernel(LatParams lp)
                 const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(s));
                 rowsum = take ? __hiloint2double(hi, lo) : rowsum;
             }
+            KMC_STAMP(5);
             wave_fence();
             rowpre = wave_scan_incl_z(rowsum, sz);
             rowex = dpp_f64<0x138, 0xF>(rowpre);
             gamma = readlane_f64(rowpre, 63);
+            KMC_STAMP(6);
         }
         // ---- flush the chunk: clock, trace, barrier diagnostics ----------------------
         done = hl;
@@ -593,6 +605,10 @@ void hop_lat_kernel(LatParams lp)
         p.hops_done[r] = hop0 + hops;
         p.n_exact[r] += n_exact;
         p.status[r] |= status;
+#ifdef KMC_STAMPS
+        if (p.stamps)
+            for (int k = 0; k < 8; ++k) p.stamps[r * 8 + k] = (long long)st_acc[k];
+#endif
     }
     if (lane == 0) p.barrier[r * 5 + 0] = b_stat;
     if (lane == 1 || lane == 4) p.barrier[r * 5 + lane] += b_stat;
