@@ -88,6 +88,14 @@ __device__ __forceinline__ double wave_scan_incl_z(double x, ScanZero& z)
 
 static_assert(sizeof(ExactParShared) <= Q64_XSCRATCH, "exact-path scratch");
 
+// first set bit of a wave mask, 63 if there is none (s_ff1_i32_b64 returns -1 for zero: no compare and select)
+__device__ __forceinline__ int q64_ff1_63(unsigned long long m)
+{
+    int r;
+    asm("s_ff1_i32_b64 %0, %1" : "=s"(r) : "s"(m));
+    return r & 63;
+}
+
 // The kernel's parameters, re-read from the kernel-argument segment (scalar loads through the constant
 // cache) where they are used outside the hop loop.  Read once at the top they occupy ~50 scalar registers
 // for the whole kernel, and the hop loop then spills and refills its own scalars through vector lanes
@@ -275,6 +283,18 @@ void hop_q64_kernel(HopParams p)
     const int wm_ext = p.window_mode == 1 ? 0 : -1;    // all-ones mask: the window extends along the hop
     const int wm_ni0 = p.window_mode == 0 ? 4 : 5;
     const int wm_nj0 = p.window_mode == 0 ? 4 : (p.window_mode == 1 ? 6 : 5);
+    // per direction d, in lane d: di, dj, the window's origin relative to the start point and its size, for the context's window
+    // mode (i_lo = i - 2 + ext * min(di, 0), n_i = ni0 + ext * |di|, same for j).  Round 3: -25 scalar instructions per hop,
+    // -3 % at 4096 replicas -- at four waves per SIMD scalar instructions take issue slots too (profiles/r3_var_geo.txt)
+    int geo;
+    {
+        const int dd = lane < 6 ? lane : 0;
+        const int gdi = ((2310 >> (2 * dd)) & 3) - 1, gdj = ((105 >> (2 * dd)) & 3) - 1;
+        const int mdi = gdi < 0 ? gdi : 0, mdj = gdj < 0 ? gdj : 0;
+        const int ilo = -2 + (wm_ext & mdi), gni = wm_ni0 + (wm_ext & gdi & 1);
+        const int jlo = -2 + (wm_ext & mdj), gnj = wm_nj0 + (wm_ext & gdj & 1);
+        geo = (gdi & 3) | ((gdj & 3) << 2) | ((ilo & 7) << 4) | ((jlo & 7) << 7) | (gni << 10) | (gnj << 13);
+    }
     const double mfac = p.mfac;
     const unsigned long long ok_mask = p.force_exact != 0 ? 0ull : ~0ull;     // kmc_set_debug: every hop through the exact path
     const bool presim = p.presim != 0;
@@ -366,7 +386,7 @@ void hop_q64_kernel(HopParams p)
             const double M = __hiloint2double(M_hi, M_lo);
             // ---- row ------------------------------------------------------
             const unsigned long long mr = ballot64(rowpre >= t);
-            const int i = (__ffsll((long long)mr) - 1) & 63;
+            const int i = q64_ff1_63(mr);
             // ---- quarter: every lane decides for its own row, lane i's answer counts ----
             const double p2 = Q0 + Q1;
             const double c1 = rowex + Q0, c2 = rowex + p2, c3 = rowex + (p2 + Q2);
@@ -415,7 +435,7 @@ void hop_q64_kernel(HopParams p)
             const double lo_l = first ? ape : a0, hi_l = first ? a0 : ap, rate_l = first ? rr.x : rr.y;
             const bool ok_l = (hi_l - t >= M) & (t - lo_l >= M) & (rate_l > 0.0);
             const unsigned long long me = ballot64(ap >= t) & 0xFFFFFFFFFFFFull;       // a0 >= t implies ap >= t
-            const int el = (__ffsll((long long)me) - 1) & 63;
+            const int el = q64_ff1_63(me);
             const unsigned long long mok = ballot64(ok_l);
             const int snd = (int)((ballot64(first) >> el) & 1ull) ^ 1;
             int pnum_lo = __builtin_amdgcn_readlane(__double2loint(rate_l), el);
@@ -478,8 +498,10 @@ void hop_q64_kernel(HopParams p)
             const int s_src = ii * 64 + j;
             const int idx = (ANY ? ii * ny + j : s_src) * 6 + d;
             // ---- update (:518-535) -------------------------------------------
-            const int di = ((2310 >> (2 * d)) & 3) - 1;          // {1, 0, -1, -1, 0, 1}
-            const int dj = ((105 >> (2 * d)) & 3) - 1;           // {0, 1, 1, 0, -1, -1}
+            // the hop's geometry (:503-504, :444-453), packed per direction in lane d of `geo` (as in kmc_hop_lat.h): one
+            // lane read and six scalar bit-field extracts instead of ~25 scalar instructions
+            const int gw = __builtin_amdgcn_readlane(geo, d);
+            const int di = __builtin_amdgcn_sbfe(gw, 0, 2), dj = __builtin_amdgcn_sbfe(gw, 2, 2);      // {1, 0, -1, -1, 0, 1}, {0, 1, 1, 0, -1, -1}
             const int ie = ii + di, je = j + dj;                 // unwrapped
             const int iw = ANY ? (ie < 0 ? ie + nx : (ie >= nx ? ie - nx : ie)) : (ie & 63);
             const int jw = ANY ? (je < 0 ? je + ny : (je >= ny ? je - ny : je)) : (je & 63);
@@ -487,9 +509,8 @@ void hop_q64_kernel(HopParams p)
             KMC_STAMP(6);
             // ---- window geometry (:444-453): group a = window row a; its lane c holds sites c and
             // c + 8 of the one or two quarters the window's columns fall in
-            const int min_di = di < 0 ? di : 0, min_dj = dj < 0 ? dj : 0;
-            const int i_lo = ii - 2 + (wm_ext & min_di), n_i = wm_ni0 + (wm_ext & di & 1);     // scalar integer ops only
-            const int j_lo = j - 2 + (wm_ext & min_dj), n_j = wm_nj0 + (wm_ext & dj & 1);
+            const int i_lo = ii + __builtin_amdgcn_sbfe(gw, 4, 3), j_lo = j + __builtin_amdgcn_sbfe(gw, 7, 3);
+            const int n_i = (int)__builtin_amdgcn_ubfe((uint32_t)gw, 10, 3), n_j = (int)__builtin_amdgcn_ubfe((uint32_t)gw, 13, 3);
             int si;                                              // this group's lattice row
             // (ANY: the window's first row and column are wrapped once, as scalars; a lane's offset then needs one compare)
             const int i_lo0 = ANY ? (i_lo < 0 ? i_lo + nx : i_lo) : 0, j_lo0 = ANY ? (j_lo < 0 ? j_lo + ny : j_lo) : 0;
