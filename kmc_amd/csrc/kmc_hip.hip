@@ -338,7 +338,24 @@ __global__ __launch_bounds__(64) void rates_cols_kernel(const uint8_t* __restric
             for (int k = 0; k < 16; ++k) c0 |= (uint64_t)(b[k] & 1u) << (i0 + k);
         }
     } else {
-        for (int i = 0; i < nx; ++i) c0 |= (uint64_t)(o[i * ny] & 1u) << i;
+        // every row's load in flight at once, issued in uniform groups of 16 (rows beyond nx are not read): as one loop over
+        // the rows the loads ran one after the other, and the fill of 4096 x 30x30 took as long as that of 4096 x 64x64
+        uint32_t b[64];
+#pragma unroll
+        for (int i0 = 0; i0 < 64; i0 += 16) {
+            if (i0 < nx) {                                   // uniform
+#pragma unroll
+                for (int k = 0; k < 16; ++k) b[i0 + k] = o[(i0 + k < nx ? i0 + k : nx - 1) * ny];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) b[i0 + k] = 0u;
+            }
+        }
+        uint32_t half[2] = {0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 64; ++k) half[k >> 5] |= (b[k] & 1u) << (k & 31);
+        c0 = ((uint64_t)half[1] << 32) | half[0];
+        if (nx < 64) c0 &= (1ull << nx) - 1ull;
     }
     if (!live) c0 = 0;
     // neighbouring columns j +- 1, j +- 2 (periodic in ny)
@@ -349,45 +366,163 @@ __global__ __launch_bounds__(64) void rates_cols_kernel(const uint8_t* __restric
         const int hi = __builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)(c0 >> 32));
         return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
     };
-    const uint64_t p2 = from(2), p1 = from(1), m1 = from(-1), m2 = from(-2);
+    uint64_t p2 = 0, p1 = 0, m1 = 0, m2 = 0;
+    if (NX) { p2 = from(2); p1 = from(1); m1 = from(-1); m2 = from(-2); }
     uint32_t* out = keys + (live ? (size_t)r * n + lane : 0);
-    // window of column c at row i: bits (i-2 .. i+2) mod nx.  Rotate every column left by 2 once, so that bit i of the
-    // rotated bitmap is row i - 2; rows whose window runs over the top take it from a second copy rotated by 32 more.
+    // Window of column c at row i: bits (i-2 .. i+2) mod nx.  The key has six fields, each a run of window bits of one column
+    // (the key's chars run column by column, kmc_device.h key_from_cols):
+    //   column j+2 bits 0-2 -> key 15-17 | j+1 bits 0-3 -> 11-14 | j bits 3-4 -> 9-10 | j bits 0-1 -> 7-8 | j-1 bits 1-4 -> 3-6 |
+    //   j-2 bits 2-4 -> 0-2;  the site itself is bit 2 of column j's window.
+    // Every field gets a copy of its column rotated so that bit i + P of the copy is row i - 2, P = the field's place in the key
+    // minus its first window bit: one v_alignbit by the row number then drops the field IN PLACE, and a key is 6 alignbits, 6
+    // and / and-or, and 2 instructions for the vacancy (round 3: 15 vector instructions per key instead of 22; the kernel is
+    // bound by their issue, not by HBM: profiles/r3_stream_floor.txt has what a plain copy of the same bytes reaches).
+    constexpr int FP[6] = {15, 11, 6, 7, 2, -2};
+    constexpr uint32_t FM[6] = {0x38000u, 0x7800u, 0x600u, 0x180u, 0x78u, 0x7u};
     auto rotl = [&](uint64_t c, int k) -> uint64_t {        // rotate left by k within nx bits, 0 < k < nx
         const uint64_t m = nx == 64 ? ~0ull : ((1ull << nx) - 1ull);
         return ((c << k) | (c >> (nx - k))) & m;
     };
-    if (NX == 64) {
-        const uint64_t a[5] = {rotl(p2, 2), rotl(p1, 2), rotl(c0, 2), rotl(m1, 2), rotl(m2, 2)};
-        uint64_t b[5];
+    auto emit = [&](int i, const uint32_t x[6]) {
+        uint32_t key = x[0] & FM[0];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) b[k] = (a[k] >> 32) | (a[k] << 32);
+        for (int f = 1; f < 6; ++f) key |= x[f] & FM[f];
+        // vacant site -> KMC_VACANT (all ones): the site's bit sits at bit 9 of field 3's word
+        key |= ~(uint32_t)__builtin_amdgcn_sbfe((int)x[3], 9u, 1u);
+        // (streaming stores: the fill writes 4 B per site that nothing reads before the whole array is written; without
+        // the hint the stream ran at 0.59 of the HBM peak, with it at 0.69, 0.82 on 16 384 replicas)
+        if (live) __builtin_nontemporal_store(key, &out[i * ny]);
+    };
+    if (NX == 64) {
+        const uint64_t col[6] = {p2, p1, c0, c0, m1, m2};
+        uint32_t lo[6], hi[6];
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            const uint64_t a = FP[f] + 2 ? rotl(col[f], FP[f] + 2) : col[f];
+            lo[f] = (uint32_t)a; hi[f] = (uint32_t)(a >> 32);
+        }
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
-            uint32_t w[5];
+            uint32_t x[6];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const uint64_t v = i < 32 ? a[k] : b[k];
-                w[k] = __builtin_amdgcn_alignbit((uint32_t)(v >> 32), (uint32_t)v, (uint32_t)(i & 31));
-            }
-            uint32_t key = ((w[0] & 7u) << 15) | ((w[1] & 15u) << 11) | (((w[2] >> 3) & 3u) << 9) | ((w[2] & 3u) << 7) |
-                           (((w[3] >> 1) & 15u) << 3) | ((w[4] >> 2) & 7u);
-            key = ((w[2] >> 2) & 1u) ? key : KMC_VACANT;
-            // (streaming stores: the fill writes 4 B per site that nothing reads before the whole array is written; without
-            // the hint the stream ran at 0.59 of the HBM peak, with it at 0.69, 0.82 on 16 384 replicas)
-            if (live) __builtin_nontemporal_store(key, &out[i * 64]);
+            for (int f = 0; f < 6; ++f)       // rows >= 32 take the window from the copy rotated by 32 more: the dwords swapped
+                x[f] = i < 32 ? __builtin_amdgcn_alignbit(hi[f], lo[f], (uint32_t)i) : __builtin_amdgcn_alignbit(lo[f], hi[f], (uint32_t)(i - 32));
+            emit(i, x);
         }
     } else {
-        for (int i = 0; i < nx; ++i) {
-            int st = i - 2;
-            if (st < 0) st += nx;
-            const int sl = (nx - st) & 63;
-            auto win = [&](uint64_t c) -> uint32_t { return (uint32_t)((c >> st) | (c << sl)) & 31u; };
-            const uint32_t w2 = win(p2), w1 = win(p1), w0 = win(c0), v1 = win(m1), v2 = win(m2);
-            uint32_t key = ((w2 & 7u) << 15) | ((w1 & 15u) << 11) | (((w0 >> 3) & 3u) << 9) | ((w0 & 3u) << 7) |
-                           (((v1 >> 1) & 15u) << 3) | ((v2 >> 2) & 7u);
-            key = ((w0 >> 2) & 1u) ? key : KMC_VACANT;
-            if (live) __builtin_nontemporal_store(key, &out[i * ny]);
+        // any nx <= 64: the column rotated left by 2 is continued periodically over 96 bits (three dwords), so that the window
+        // of row i is bits i .. i + 4 whatever nx is.  The lane continues its own column and fetches the neighbours' three
+        // dwords (the 64-bit shifts of the continuation are slow instructions); the six placed copies are 96-bit shifts of those.
+        // (Round 3: two 64-bit shifts per column and row stood here, and the rows' loads ran one after the other:
+        // 4096 x 30x30 took 13.3 us, as long as 4096 x 64x64.)
+        uint32_t e[5][3];
+        {
+            const uint64_t a = rotl(c0, 2);
+            uint64_t lo = 0, hi = 0;                         // bits 0 .. 63 and 64 .. 127 of the periodic continuation
+            for (int sh = 0; sh < 96; sh += nx) {
+                if (sh < 64) { lo |= a << sh; if (sh) hi |= a >> (64 - sh); }
+                else hi |= a << (sh - 64);
+            }
+            e[2][0] = (uint32_t)lo; e[2][1] = (uint32_t)(lo >> 32); e[2][2] = (uint32_t)hi;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            if (k == 2) continue;
+            int src = lane + (2 - k);                        // k = 0 .. 4: columns j + 2, j + 1, j, j - 1, j - 2
+            src = lane0 + (src < 0 ? src + ny : (src >= ny ? src - ny : src));
+#pragma unroll
+            for (int w = 0; w < 3; ++w) e[k][w] = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)e[2][w]);
+        }
+        constexpr int FC[6] = {0, 1, 2, 2, 3, 4};           // the field's column in e[]
+        uint32_t g[6][3];
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            const uint32_t* c = e[FC[f]];
+            if (FP[f] > 0) {
+                g[f][0] = c[0] << FP[f];
+                g[f][1] = __builtin_amdgcn_alignbit(c[1], c[0], 32u - (uint32_t)FP[f]);
+                g[f][2] = __builtin_amdgcn_alignbit(c[2], c[1], 32u - (uint32_t)FP[f]);
+            } else {
+                g[f][0] = __builtin_amdgcn_alignbit(c[1], c[0], (uint32_t)-FP[f]);
+                g[f][1] = __builtin_amdgcn_alignbit(c[2], c[1], (uint32_t)-FP[f]);
+                g[f][2] = c[2] >> -FP[f];
+            }
+        }
+        const int n_lo = nx < 32 ? nx : 32;
+        for (int i = 0; i < n_lo; ++i) {
+            uint32_t x[6];
+#pragma unroll
+            for (int f = 0; f < 6; ++f) x[f] = __builtin_amdgcn_alignbit(g[f][1], g[f][0], (uint32_t)i);
+            emit(i, x);
+        }
+        for (int i = 32; i < nx; ++i) {
+            uint32_t x[6];
+#pragma unroll
+            for (int f = 0; f < 6; ++f) x[f] = __builtin_amdgcn_alignbit(g[f][2], g[f][1], (uint32_t)(i - 32));
+            emit(i, x);
+        }
+    }
+}
+
+// Rows R1, R2 for lattices beyond 64 x 64 (config 4's 1024 x 1024, the 256 x 256 ensembles): one wave = a tile of TI rows x 64
+// columns of one replica, in registers like rates_cols_kernel.  Lane = lattice column j0 + lane: bit k of its bitmap is row
+// i0 - 2 + k (TI + 4 <= 32 rows: one dword), built from coalesced byte loads (a wave-instruction reads 64 contiguous bytes of
+// a lattice row); lanes 0 .. 3 also build the four halo columns j0 - 2, j0 - 1, j0 + 64, j0 + 65.  A key is then six bit
+// fields at immediate positions of five registers, and a wave-instruction stores 256 contiguous bytes.  TI is picked by the
+// host so that the launch has enough waves for the chip (a 1024 x 1024 lattice is 1376 tiles of 12 rows).
+// (Round 3: rates_full_kernel -- byte tiles in LDS, 18 one-byte LDS reads per key -- took 18.6 us for 64 x 256 x 256 and 8.6 us
+// for one 1024 x 1024 where a plain copy of the same bytes takes 6.7 / 6.4, 5.9 of which is the empty launch:
+// profiles/r3_stream_floor.txt.)
+template <int TI>
+__global__ __launch_bounds__(64) void rates_tile_kernel(const uint8_t* __restrict__ occ, int nx, int ny, int tiles_i, int tiles_j,
+                                                         uint32_t* __restrict__ keys)
+{
+    static_assert(TI + 4 <= 32, "a tile's rows and its halo are one dword per column");
+    int b = blockIdx.x;
+    const int tj = b % tiles_j; b /= tiles_j;
+    const int ti = b % tiles_i;
+    const int r = b / tiles_i;
+    const int lane = threadIdx.x, i0 = ti * TI, j0 = tj * 64;
+    const size_t n = (size_t)nx * ny;
+    const uint8_t* o = occ + (size_t)r * n;
+    const int gj = j0 + lane;
+    const int gjc = gj < ny ? gj : gj % ny;                 // lanes beyond the lattice hold the wrapped columns (ny < 64 included)
+    int hj = lane < 2 ? j0 - 2 + lane : j0 + 62 + lane;     // lanes 0 .. 3: columns j0 - 2, j0 - 1, j0 + 64, j0 + 65
+    hj = ((hj % ny) + ny) % ny;
+    const bool halo = lane < 4;
+    uint32_t c = 0, h = 0;
+    {
+        int gi = i0 - 2;
+        if (gi < 0) gi += nx;                               // i0 - 2 >= -2 and nx >= 5
+        uint32_t bc[TI + 4], bh[TI + 4];
+#pragma unroll
+        for (int k = 0; k < TI + 4; ++k) {
+            const uint8_t* rowp = o + (size_t)gi * ny;      // uniform
+            bc[k] = rowp[gjc];
+            bh[k] = halo ? rowp[hj] : 0u;
+            ++gi;
+            if (gi == nx) gi = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < TI + 4; ++k) { c |= (bc[k] & 1u) << k; h |= (bh[k] & 1u) << k; }
+    }
+    const uint32_t h0 = __builtin_amdgcn_readlane(h, 0), h1 = __builtin_amdgcn_readlane(h, 1),
+                   h2 = __builtin_amdgcn_readlane(h, 2), h3 = __builtin_amdgcn_readlane(h, 3);
+    auto from = [&](int dj) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + dj) & 63) << 2, (int)c); };
+    uint32_t m1 = from(-1), m2 = from(-2), p1 = from(1), p2 = from(2);
+    m1 = lane == 0 ? h1 : m1;
+    m2 = lane == 0 ? h0 : (lane == 1 ? h1 : m2);
+    p1 = lane == 63 ? h2 : p1;
+    p2 = lane == 62 ? h2 : (lane == 63 ? h3 : p2);
+    const bool live = gj < ny;
+    uint32_t* out = keys + (size_t)r * n + (size_t)i0 * ny + (live ? gj : 0);
+#pragma unroll
+    for (int a = 0; a < TI; ++a) {
+        if (i0 + a < nx) {                                  // uniform
+            uint32_t key = (((p2 >> a) & 7u) << 15) | (((p1 >> a) & 15u) << 11) | (((c >> (a + 3)) & 3u) << 9) | (((c >> a) & 3u) << 7) |
+                           (((m1 >> (a + 1)) & 15u) << 3) | ((m2 >> (a + 2)) & 7u);
+            key = ((c >> (a + 2)) & 1u) ? key : KMC_VACANT;
+            if (live) __builtin_nontemporal_store(key, out + (size_t)a * ny);
         }
     }
 }
@@ -1121,8 +1256,23 @@ static int launch_rates_full(kmc_ctx* c, double* P)
             rates_cols_kernel<64><<<c->R, 64, 0, c->stream>>>(c->occ, c->R, c->nx, c->ny, c->keys);
         else {
             const int per_wave = c->ny <= 16 ? 4 : (c->ny <= 32 ? 2 : 1);
+            // (two or four waves sharing a lattice's rows, for more waves on the chip, are slower: 4096 x 30x30 10.8 us with one,
+            // 11.2 with two, 13.2 with four)
             rates_cols_kernel<0><<<(c->R + per_wave - 1) / per_wave, 64, 0, c->stream>>>(c->occ, c->R, c->nx, c->ny, c->keys);
         }
+        HIPCHK(c, hipGetLastError());
+        return KMC_OK;
+    }
+    if (!P && c->nx >= 5 && c->ny >= 5) {
+        // tiles of 28 rows when that still gives the chip 32 waves per CU, else of 12
+        const int tj = (c->ny + 63) / 64;
+        const long long b28 = (long long)c->R * ((c->nx + 27) / 28) * tj, b12 = (long long)c->R * ((c->nx + 11) / 12) * tj;
+        if (b12 > 0x7fffffffLL) return fail(c, KMC_EINVAL, "rates_full: grid too large");
+        if (b12 < 4096) {
+            const long long b4 = (long long)c->R * ((c->nx + 3) / 4) * tj;
+            rates_tile_kernel<4><<<(unsigned)b4, 64, 0, c->stream>>>(c->occ, c->nx, c->ny, (c->nx + 3) / 4, tj, c->keys);
+        } else if (b28 >= 8192) rates_tile_kernel<28><<<(unsigned)b28, 64, 0, c->stream>>>(c->occ, c->nx, c->ny, (c->nx + 27) / 28, tj, c->keys);
+        else rates_tile_kernel<12><<<(unsigned)b12, 64, 0, c->stream>>>(c->occ, c->nx, c->ny, (c->nx + 11) / 12, tj, c->keys);
         HIPCHK(c, hipGetLastError());
         return KMC_OK;
     }

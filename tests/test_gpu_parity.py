@@ -79,7 +79,8 @@ def test_rate_generation(kmc, tables):
 
 
 # ---------------------------------------------------------------- rows R1-R3
-@pytest.mark.parametrize('shape', [(10, 10), (30, 30), (64, 64), (8, 12), (5, 7), (100, 37), (3, 3), (130, 70)])
+@pytest.mark.parametrize('shape', [(10, 10), (30, 30), (64, 64), (8, 12), (5, 7), (100, 37), (3, 3), (130, 70), (64, 30), (61, 64),
+                                   (33, 16), (70, 5), (5, 100), (256, 256), (300, 260)])
 def test_rates_full(kmc, tables, dense, shape):
     nx, ny = shape
     rs = np.random.RandomState(nx * 1000 + ny)
@@ -105,6 +106,20 @@ def test_rates_full(kmc, tables, dense, shape):
             k, rates = eng.site_probability(2, i, j)
             assert k == O.site_key(occ[2], i, j)
             assert np.array_equal(rates, dense[k])
+
+
+def test_rates_full_many_tiles(kmc, tables, dense):
+    """Rows R1, R2 on an ensemble large enough for the 28-row tiles of rates_tile_kernel (>= 8192 of them), and on an
+    ensemble of 30 x 30 lattices packed two to a wave: a sample of the replicas against the oracle."""
+    for (R, nx, ny) in ((1500, 70, 66), (1031, 30, 30), (517, 9, 13)):
+        rs = np.random.RandomState(R)
+        occ = (rs.rand(R, nx, ny) < rs.rand(R, 1, 1)).astype(np.int8)
+        with make_engine(kmc, tables, R, nx, ny) as eng:
+            eng.set_lattice(occ)
+            eng.rates_full()
+            keys = eng.get_keys()
+        for r in [0, 1, R - 2, R - 1] + list(rs.randint(0, R, 12)):
+            assert np.array_equal(keys[r], O.all_keys(occ[r])), (R, nx, ny, r)
 
 
 @pytest.mark.parametrize('mode', ['hex_ref', 'obj_ref', 'full'])
