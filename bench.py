@@ -522,7 +522,8 @@ def d_star_check_run(kmc_amd, np, local_rank, base512, n_replicas=4, sim_steps=4
 def occupancy_of(kernel, R):
     """(waves per SIMD, SIMDs that hold a wave) of a launch of R one-wave replicas of `kernel` on the 256 CUs."""
     if kernel.startswith('hop_big') or kernel.startswith('hop_global'):
-        return 1, min(R, N_CU) * 4                            # one 256-thread workgroup per lattice: a wave on each SIMD
+        return 1, min(R, N_CU) * 4                            # one workgroup per lattice, on all four SIMDs of its CU (wave 0 runs
+                                                              # the hop loop, the others sleep outside the exact replay)
     per_cu = 1 if kernel.startswith('hop_lat') else 16
     waves_cu = max(1, min(per_cu, -(-R // N_CU)))
     simds = min(R, N_CU * 4) if waves_cu >= 4 else min(R, N_CU * waves_cu)

@@ -26,13 +26,14 @@
 
 namespace kmc {
 
-#define KMC_XP_WAVES 4                       // at most
+#define KMC_XP_WAVES 4                       // of the common instance (the large-lattice kernel may use more)
 #define KMC_XP_NOEV 0xFFFFFFFFFFFFFFFFull
 
-struct ExactParShared {
-    double chunk_sum[KMC_XP_WAVES];
-    long long wave_tot[2][KMC_XP_WAVES];     // double-buffered: one barrier per event-free tile
-    int wave_flag[2][KMC_XP_WAVES];
+template <int W>
+struct ExactParSharedT {
+    double chunk_sum[W];
+    long long wave_tot[2][W];                // double-buffered: one barrier per event-free tile
+    int wave_flag[2][W];
     unsigned long long ev;                   // earliest event of the pass: entry index << 1 | type
     double c;                                // exact cumsum in front of entry `pos`
     long long pos;
@@ -41,6 +42,7 @@ struct ExactParShared {
     int done;
     PwFrame frames[KMC_PW_DEPTH];
 };
+typedef ExactParSharedT<KMC_XP_WAVES> ExactParShared;
 
 #ifdef KMC_XP_TRACE
 __device__ volatile long long* g_xp_trace = nullptr;      // scripts/probes/xp_probe.hip: progress in pinned host memory
@@ -99,13 +101,9 @@ __device__ __forceinline__ double xp_leaf128(KeyFn keys, const double* __restric
 
 // The same leaf with run-time loops and 8 loads in flight: ~40 registers instead of ~170, for callers
 // that must stay inside a small register budget (hop_q64_kernel: 128).
-template <class KeyFn>
-__device__ __forceinline__ double xp_leaf128_lean(KeyFn keys, const double* __restrict__ table, long lo)
+template <class EntryFn>
+__device__ __forceinline__ double xp_leaf128_lean(EntryFn entry, long lo)
 {
-    auto entry = [&](long e) -> double {
-        const long s = e / 6;
-        return table[(size_t)xp_row(keys(s)) * 6 + (int)(e - 6 * s)];
-    };
     double r0 = entry(lo), r1 = entry(lo + 1), r2 = entry(lo + 2), r3 = entry(lo + 3),
            r4 = entry(lo + 4), r5 = entry(lo + 5), r6 = entry(lo + 6), r7 = entry(lo + 7);
 #pragma unroll 1
@@ -158,12 +156,60 @@ __device__ __forceinline__ long long wave_scan_incl_i64(long long x)
 // three, and the replay is bound by exactly those (one CU takes ~0.5 scattered 16-byte requests per cycle) -- and summed;
 // only a tile that holds an event (a binade crossing, a tie, the stop: ~60 of the 1000 tiles of a 1024 x 1024 replay) is
 // read again in the owner layout below, where every thread holds consecutive entries and the event's place can be found.
+//
+// Where the rates come from is a policy (Rows): XpRowsTable gathers the 48-byte table row behind a site's 18-bit key (every
+// kernel's state); XpRowsPalette reads the site's six 10-bit palette indices from a per-site array and looks the rates up in
+// a palette in LDS (hop_big_kernel's SITEW instances: a replay then STREAMS 8 of every 16 contiguous bytes instead of
+// gathering a scattered table row per site, which is what bounded it at 1024 x 1024).
+template <class KeyFn> struct XpRowsTable {
+    KeyFn keys;
+    const double* __restrict__ table;
+    typedef uint32_t key_t;
+    static constexpr bool WHOLE = false;                  // striped reading: three lanes share a row's three 16-byte pieces
+    static constexpr bool HAS_TABLE = true;
+    __device__ __forceinline__ key_t none() const { return KMC_VACANT; }
+    __device__ __forceinline__ key_t key(long s) const { return keys(s); }
+    __device__ __forceinline__ bool live(key_t k) const { return k <= 0x3FFFFu; }
+    __device__ __forceinline__ double2 piece(key_t k, int part) const
+    {
+        return *reinterpret_cast<const double2*>(table + (size_t)k * 6 + 2 * part);
+    }
+    __device__ __forceinline__ double entry(long e) const
+    {
+        const int s = (int)(e / 6);
+        const int d = (int)(e - 6 * (long)s);
+        return table[(size_t)xp_row(keys(s)) * 6 + d];
+    }
+};
+
+struct XpSiteWord { double w; unsigned long long rp; };   // = LatWP (kmc_hop_lat.h): {W, six 10-bit palette indices}
+struct XpRowsPalette {
+    const XpSiteWord* __restrict__ sw;                    // per site
+    const __attribute__((address_space(3))) double* pal;  // in LDS (typed so: a generic pointer makes every look-up a flat load); pal[0] = 0.0
+    typedef unsigned long long key_t;
+    static constexpr bool WHOLE = true;                   // a lane reads whole rows: consecutive lanes, consecutive sites
+    static constexpr bool HAS_TABLE = false;
+    __device__ __forceinline__ key_t none() const { return 0ull; }
+    __device__ __forceinline__ key_t key(long s) const { return sw[s].rp; }
+    __device__ __forceinline__ bool live(key_t k) const { return k != 0ull; }      // all six rates zero otherwise
+    __device__ __forceinline__ double2 piece(key_t k, int part) const
+    {
+        return make_double2(pal[(uint32_t)(k >> (20 * part)) & 1023u], pal[(uint32_t)(k >> (20 * part + 10)) & 1023u]);
+    }
+    __device__ __forceinline__ double entry(long e) const
+    {
+        const long s = e / 6;
+        const int d = (int)(e - 6 * s);
+        return pal[(uint32_t)(sw[s].rp >> (10 * d)) & 1023u];
+    }
+};
+
 #define XP_SYNC() do { if (NW == 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); else __syncthreads(); } while (0)
-template <int NW, int KMC_XP_SITES, bool LEAN, bool STRIPED = false, class KeyFn>     // KMC_XP_SITES = sites per thread and tile
-__device__ __forceinline__ void exact_select_par_impl(KeyFn keys, const double* __restrict__ table,
-                                                      int n, double rho, ExactParShared* sh,
-                                                      double gamma_hint = 0.0, double delta = 0.0)
+template <int NW, int KMC_XP_SITES, bool LEAN, bool STRIPED = false, class Rows, class Shared>      // KMC_XP_SITES = sites per thread and tile
+__device__ __forceinline__ void exact_select_rows_impl(Rows rows, int n, double rho, Shared* sh,
+                                                       double gamma_hint = 0.0, double delta = 0.0)
 {
+    typedef typename Rows::key_t key_t;
     constexpr int XP_THREADS = 64 * NW;
     constexpr long XP_TILE = (long)XP_THREADS * KMC_XP_SITES * 6;
     // NW == 1: the caller is ONE wave, possibly of a workgroup that holds other waves doing something else (hop_lat_kernel's
@@ -172,11 +218,7 @@ __device__ __forceinline__ void exact_select_par_impl(KeyFn keys, const double* 
 #ifdef KMC_XP_TRACE
     const unsigned long long xp_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    auto entry = [&](long e) -> double {
-        const int s = (int)(e / 6);
-        const int d = (int)(e - 6 * (long)s);
-        return table[(size_t)xp_row(keys(s)) * 6 + d];
-    };
+    auto entry = [&](long e) -> double { return rows.entry(e); };
     // ---- np.sum: full 8192-element buffers, one wave each (lane = 128-element leaf)
     const long n6 = 6L * n;
     const long nfull = n6 / 8192;
@@ -189,8 +231,8 @@ restart:
             const long lo = c * 8192 + (long)lane * 128;
             const int o = (int)(lo % 6);                  // 0, 2 or 4: 8192 and 128 are both 2 (mod 6)
             double res;
-            if (LEAN) res = xp_leaf128_lean(keys, table, lo);
-            else res = o == 0 ? xp_leaf128<0>(keys, table, lo) : (o == 2 ? xp_leaf128<2>(keys, table, lo) : xp_leaf128<4>(keys, table, lo));
+            if constexpr (LEAN || !Rows::HAS_TABLE) res = xp_leaf128_lean(entry, lo);
+            else res = o == 0 ? xp_leaf128<0>(rows.keys, rows.table, lo) : (o == 2 ? xp_leaf128<2>(rows.keys, rows.table, lo) : xp_leaf128<4>(rows.keys, rows.table, lo));
             // pairwise tree over the 64 leaves: lower half + upper half at every level
             for (int b = 1; b < 64; b <<= 1) {
                 const double other = __shfl_xor(res, b, 64);
@@ -240,23 +282,25 @@ restart:
     const long long two53 = 1LL << 53, two54 = 1LL << 54;
     const double magic = 4503599627370496.0;              // 2^52
 
-    uint32_t knext[KMC_XP_SITES];
+    key_t knext[KMC_XP_SITES];
 #pragma unroll
     for (int q = 0; q < KMC_XP_SITES; ++q) {
         const long s = (long)tid * KMC_XP_SITES + q;
-        knext[q] = (!STRIPED && s < n) ? keys(s) : KMC_VACANT;
+        knext[q] = (!STRIPED && s < n) ? rows.key(s) : rows.none();
     }
     // striped reading: piece tid + XP_THREADS * m of the tile = part (piece % 3) of site (piece / 3)
     constexpr int NP = KMC_XP_SITES * 3;                  // 16-byte pieces per thread and tile
-    uint32_t kstr[STRIPED ? NP : 1];
+    key_t kstr[STRIPED ? NP : 1];
     const int tid_part = tid % 3, tid_site = tid / 3;
-    auto stripe_part = [&](int m) -> int { return (tid_part + m * (XP_THREADS % 3)) % 3; };
-    auto stripe_site = [&](int m) -> long { return (long)(m * XP_THREADS + tid) / 3; };
+    // (Rows::WHOLE: pieces 3 q .. 3 q + 2 are the three parts of the thread's q-th site, site number q * XP_THREADS + tid)
+    auto stripe_part = [&](int m) -> int { return Rows::WHOLE ? m % 3 : (tid_part + m * (XP_THREADS % 3)) % 3; };
+    auto stripe_site = [&](int m) -> long { return Rows::WHOLE ? (long)((m / 3) * XP_THREADS + tid) : (long)(m * XP_THREADS + tid) / 3; };
     auto stripe_keys = [&](long t0) {
 #pragma unroll
         for (int m = 0; m < NP; ++m) {
             const long s = t0 / 6 + stripe_site(m);
-            kstr[m] = s < n ? keys(s) : KMC_VACANT;
+            if (Rows::WHOLE && m % 3) kstr[m] = kstr[m - 1];
+            else kstr[m] = s < n ? rows.key(s) : rows.none();
         }
     };
     (void)tid_site;
@@ -269,8 +313,7 @@ restart:
 #pragma unroll
         for (int m = 0; m < NP; ++m) {
             dst[m] = make_double2(0.0, 0.0);               // vacant, or beyond the lattice: zeros, no request
-            if (kstr[m] <= 0x3FFFFu)
-                dst[m] = *reinterpret_cast<const double2*>(table + (size_t)kstr[m] * 6 + 2 * stripe_part(m));
+            if (rows.live(kstr[m])) dst[m] = rows.piece(kstr[m], stripe_part(m));
         }
     };
     // The running state (c, pos) is uniform and lives in registers: every thread derives it from the
@@ -324,23 +367,22 @@ restart:
 #pragma unroll
             for (int q = 0; q < KMC_XP_SITES; ++q) {
                 const long s = e0 / 6 + q;
-                knext[q] = s < n ? keys(s) : KMC_VACANT;
+                knext[q] = s < n ? rows.key(s) : rows.none();
             }
         }
         double p[KMC_XP_SITES * 6];
 #pragma unroll
         for (int q = 0; q < KMC_XP_SITES; ++q) {
             double2 a = make_double2(0, 0), b = a, cc = a;
-            if (knext[q] <= 0x3FFFFu) {                        // vacant: zeros, no request
-                const double2* t = reinterpret_cast<const double2*>(table + (size_t)knext[q] * 6);
-                a = t[0]; b = t[1]; cc = t[2];
+            if (rows.live(knext[q])) {                         // vacant: zeros, no request
+                a = rows.piece(knext[q], 0); b = rows.piece(knext[q], 1); cc = rows.piece(knext[q], 2);
             }
             p[q * 6 + 0] = a.x; p[q * 6 + 1] = a.y; p[q * 6 + 2] = b.x; p[q * 6 + 3] = b.y; p[q * 6 + 4] = cc.x; p[q * 6 + 5] = cc.y;
         }
 #pragma unroll
         for (int q = 0; q < KMC_XP_SITES; ++q) {          // the next tile's keys travel while this one is summed
             const long s = (e0 + XP_TILE) / 6 + q;
-            knext[q] = (!STRIPED && s < n) ? keys(s) : KMC_VACANT;
+            knext[q] = (!STRIPED && s < n) ? rows.key(s) : rows.none();
         }
         const long hi_l = tile_end - e0;
         const int hi_m = hi_l < 0 ? 0 : (hi_l > NE ? NE : (int)hi_l);      // my entries [lo_m, hi_m) are live
@@ -455,6 +497,16 @@ restart:
         if (sh->done == 3) { XP_SYNC(); fast = false; total = 0.0; goto restart; }
     }
     XP_TRACE(6, __builtin_amdgcn_s_memtime() - xp_t0);
+}
+
+// the form every kernel but the SITEW instances of hop_big_kernel uses: rows gathered from the dense table by key
+template <int NW, int KMC_XP_SITES, bool LEAN, bool STRIPED = false, class KeyFn, class Shared>
+__device__ __forceinline__ void exact_select_par_impl(KeyFn keys, const double* __restrict__ table,
+                                                      int n, double rho, Shared* sh,
+                                                      double gamma_hint = 0.0, double delta = 0.0)
+{
+    XpRowsTable<KeyFn> rows = {keys, table};
+    exact_select_rows_impl<NW, KMC_XP_SITES, LEAN, STRIPED>(rows, n, rho, sh, gamma_hint, delta);
 }
 
 // the 256-thread instance of hop_global_kernel (striped tiles, short form on request); keys in global memory,

@@ -52,6 +52,8 @@ struct kmc_ctx {
     bool big_ok, use_big;  // larger lattices whose bitmaps fit LDS: kmc_hop_big.h (else kmc_hop_global.h)
     BigGeom geom;
     double* hier;          // [R][geom.hier_doubles] sum tree of hop_big_kernel (lazy, zeroed once)
+    LatWP* sw;             // [R][n] per-site {W, palette indices} of hop_big_kernel's SITEW instances (lazy)
+    bool big_sitew_ok, big_tree;   // SITEW possible for this lattice; kmc_set_hop_kernel(2): the round-2 instances anyway
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     bool timed;
@@ -921,6 +923,11 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
             CREATE_CHK(hipFuncSetAttribute((const void*)hop_big_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, c->geom.lds_bytes));
             CREATE_CHK(hipFuncSetAttribute((const void*)hop_big_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, c->geom.lds_bytes));
             CREATE_CHK(hipFuncSetAttribute((const void*)hop_big_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, c->geom.lds_bytes));
+            c->big_sitew_ok = big_sitew_ok(c->geom);
+            if (c->big_sitew_ok) {
+                CREATE_CHK(hipFuncSetAttribute((const void*)hop_big_kernel<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big_sitew_lds_bytes(c->geom)));
+                CREATE_CHK(hipFuncSetAttribute((const void*)hop_big_kernel<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big_sitew_lds_bytes(c->geom)));
+            }
         }
     }
     CREATE_CHK(hipStreamSynchronize(c->stream));
@@ -939,7 +946,7 @@ int kmc_destroy(kmc_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     void* bufs[] = {c->occ, c->keys, c->tags, c->table, c->wsum, c->time_total, c->step_time, c->gamma, c->hist,
                     c->hops_done, c->n_exact, c->status, c->barrier, c->scratch_d, c->draws, c->sel, c->w_g, c->tcompact, c->tcompact2, c->hier, c->xscratch,
-                    c->coll_buf, c->pool, c->wp, c->pal};
+                    c->coll_buf, c->pool, c->wp, c->pal, c->sw};
     for (void* b : bufs) if (b) hipFree(b);
     free(c->hpool);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -1052,13 +1059,15 @@ int kmc_set_hop_kernel(kmc_ctx* c, int which)
     c->qany = c->qany_ok && (which == 4 || which == 0);
     c->q64 = c->lds64 && (which == 3 || (which == 0 && c->q64_auto));
     c->use_big = c->big_ok && which != 1;
+    c->big_tree = which == 2;                  // lattices beyond 64 x 64: hop_big_kernel without the per-site words
     return KMC_OK;
 }
 
 const char* kmc_hop_kernel_name(kmc_ctx* c)
 {
     if (!c) return "none";
-    if (!c->lds_path) return c->use_big ? "hop_big_kernel" : "hop_global_kernel";
+    if (!c->lds_path)
+        return c->use_big ? (c->big_sitew_ok && !c->big_tree && c->pal_state >= 0 ? "hop_big_kernel<site words>" : "hop_big_kernel") : "hop_global_kernel";
     if (c->lat_ok && c->pal_state >= 0 && (c->lat_mode == 1 || (c->lat_mode == 0 && c->R <= KMC_LAT_AUTO_MAX && c->split != 2)))
         return c->R > KMC_LAT_ONE_PER_CU || c->lat_pk ? (c->lds64 ? "hop_lat_kernel<2 per CU>" : "hop_lat_kernel<any, 2 per CU>")
                                          : (c->lds64 ? "hop_lat_kernel" : "hop_lat_kernel<any>");
@@ -1447,6 +1456,11 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
             use_lat = false;
         }
     }
+    bool use_sitew = !c->lds_path && c->use_big && c->big_sitew_ok && !c->big_tree;
+    if (use_sitew) {
+        if (int rc = ensure_lat_tables(c)) return rc;
+        use_sitew = c->pal_state == 1;          // more than 1024 distinct rates: the round-2 instances
+    }
     const size_t Rh = (size_t)c->R * (size_t)n_hops;
     if (draws) {
         if (c->draws_cap < Rh * 2) {
@@ -1488,6 +1502,10 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         g.mfac = mfac; g.mu = ldexp(1.0, -53) * 1.001 * c->margin_scale;
         g.table = c->table; g.wsum = c->wsum; g.tcompact = c->tcompact; g.occ = c->occ; g.keys = c->keys; g.hier = c->hier;
         g.tags = c->tags;
+        if (use_sitew) {
+            if (!c->sw) HIPCHK(c, hipMalloc((void**)&c->sw, (size_t)c->R * c->n * sizeof(LatWP)));
+            g.wp = c->wp; g.pal = c->pal; g.sw = c->sw;
+        }
         g.draws = draws ? c->draws : nullptr; g.sel = sel_out ? c->sel : nullptr;
         g.seed_lo = (uint32_t)seed; g.seed_hi = (uint32_t)(seed >> 32); g.rid_base = c->rid_base;
         g.time_total = c->time_total; g.step_time = c->step_time; g.gamma = c->gamma; g.hist = c->hist;
@@ -1500,7 +1518,11 @@ static int run_impl(kmc_ctx* c, int64_t n_hops, const int64_t* counts, int presi
         c->run_groups[slot] = 1;
         HIPCHK(c, hipEventRecord(c->run_ev[slot][0][0], c->stream));
         const bool three = (c->ny & 7) != 0;                 // L1 blocks a window row can touch
-        if (c->have_compact && three)
+        if (use_sitew && three)
+            hop_big_kernel<false, 3, true><<<c->R, KMC_BIG_THREADS, big_sitew_lds_bytes(c->geom), c->stream>>>(g);
+        else if (use_sitew)
+            hop_big_kernel<false, 2, true><<<c->R, KMC_BIG_THREADS, big_sitew_lds_bytes(c->geom), c->stream>>>(g);
+        else if (c->have_compact && three)
             hop_big_kernel<true, 3><<<c->R, KMC_BIG_THREADS, c->geom.lds_bytes, c->stream>>>(g);
         else if (c->have_compact)
             hop_big_kernel<true, 2><<<c->R, KMC_BIG_THREADS, c->geom.lds_bytes, c->stream>>>(g);

@@ -16,7 +16,7 @@
 // and L3 levels exist for the climb only: a wave-wide scan skips them on the way down), certify, flip two
 // bits, recompute the <= 36 window keys from LDS bitmaps, re-sum the touched blocks from W and
 // climb the tree in registers (children prefetched before the update, DPP trees, ds_bpermute
-// between the 8-lane groups).  Waves 1-3 sleep-poll a sequence number in LDS and join only for
+// between the 8-lane groups).  The other waves sleep-poll a sequence number in LDS and join only for
 // the exact path (kmc_exact_par.h), which at 1024 x 1024 is taken by ~0.5 % of the hops: the
 // common hop contains no barrier and no forced wait on its own stores.
 //
@@ -28,11 +28,22 @@
 #include "kmc_hop_lds.h"
 #include "kmc_hop_lds64.h"
 #include "kmc_exact_par.h"
+#include "kmc_hop_lat.h"                     // LatWP, LAT_PAL_MAX: the palette form of the rate table
 
 namespace kmc {
 
-#define KMC_BIG_THREADS 256
+// waves per workgroup: wave 0 runs the hop loop, all of them the prologue, the write-back and the exact replay
+// (round 3: 8 -- two waves per SIMD bring a replay at 1024 x 1024 from 0.97 to 0.72 ms; 16, at half the registers each, 2.7 ms)
+#ifndef KMC_BIG_WAVES
+#define KMC_BIG_WAVES 8
+#endif
+#ifndef KMC_BIG_XP_SITES
+#define KMC_BIG_XP_SITES 4                   // sites per thread and tile of the replay
+#endif
+#define KMC_BIG_THREADS (64 * KMC_BIG_WAVES)
 #define KMC_BIG_VAC 0x7FFFFu                 // table row of a vacant site (all zeros), see K64_VAC
+
+typedef ExactParSharedT<KMC_BIG_WAVES> BigXpShared;
 
 struct BigGeom {
     int nx, ny, n;
@@ -59,7 +70,7 @@ __host__ __device__ inline bool big_geometry(int nx, int ny, BigGeom* g)
     g->offRow = o; o += (long long)g->nr1 * 8;
     g->offR1 = o; o += (long long)g->nr2 * 8;
     g->hier_doubles = o;
-    const long long lds = ((((long long)(ny + 4) * g->cw * 4) + 15) & ~15LL) + 256 + (((long long)sizeof(ExactParShared) + 15) & ~15LL) +
+    const long long lds = ((((long long)(ny + 4) * g->cw * 4) + 15) & ~15LL) + 640 + (((long long)sizeof(BigXpShared) + 15) & ~15LL) +
                           ((long long)g->nr1 * 8 + (long long)g->nr2 * 8) * 8 + 64;
     g->lds_bytes = (int)lds;
     return nx >= 5 && ny >= 5 && nb3 <= 8 && g->nr2 <= 64 && lds <= 160 * 1024;
@@ -87,6 +98,11 @@ struct HopBigParams {
     long long* n_exact; int* status; double* barrier;
     long long* stamps;           // [R][8] cycles per segment (-DKMC_STAMPS builds) or null
     uint32_t rid_base;           // global id of replica 0 (see HopParams)
+    // SITEW instances (round 3): the palette form of the table (hop_lat_kernel's: WP[key] = {W, six 10-bit palette indices},
+    // the palette itself in LDS) and the per-site copy SW[site] = WP[key of the site], which the hop loop keeps current
+    const LatWP* wp;
+    const double* pal;           // [LAT_PAL_MAX]
+    LatWP* sw;                   // [R][n]
 };
 
 struct BigCtrl {                 // wave 0 -> the helper waves
@@ -94,7 +110,12 @@ struct BigCtrl {                 // wave 0 -> the helper waves
     int n_li;                    // Li atoms of the lattice (conserved)
     double rho, gam;             // the draw and the tree's gamma of the hop to replay
     uint32_t kscr[6 * 8];        // new keys of the window, [window row][window column]
+    double wscr[6 * 8];          // SITEW: their W instead
 };
+#define KMC_BIG_CTRL_BYTES 640
+// SITEW: the palette behind everything else
+__host__ __device__ inline int big_sitew_lds_bytes(const BigGeom& g) { return g.lds_bytes + LAT_PAL_MAX * 8; }
+__host__ __device__ inline bool big_sitew_ok(const BigGeom& g) { return g.S1 <= 128 && big_sitew_lds_bytes(g) <= 160 * 1024; }
 
 // Parameters used at chunk boundaries and at the ends of the kernel only are re-read from the kernel-argument
 // segment there (scalar loads through the constant cache) instead of occupying scalar registers for the whole hop
@@ -112,18 +133,35 @@ __device__ __forceinline__ big_params_ptr big_cold_params()
 // The exact path of this kernel (all four waves).  gamma_hint > 0: the short form of kmc_exact_par.h, which skips the
 // np.sum pass (two thirds of a replay at 1024 x 1024) unless an entry falls inside the band that np.sum decides.
 __device__ __noinline__ void exact_select_big(const uint32_t* __restrict__ keys, const double* __restrict__ table,
-                                              int n, double rho, ExactParShared* sh, double gamma_hint, double delta)
+                                              int n, double rho, BigXpShared* sh, double gamma_hint, double delta)
 {
 #ifdef KMC_BIG_XP_OWNER         // scripts/variants_big.py: A/B against the owner layout only
-    exact_select_par_impl<4, 4, false, false>([&](long s) -> uint32_t { return keys[s]; }, table, n, rho, sh, gamma_hint, delta);
+    exact_select_par_impl<KMC_BIG_WAVES, KMC_BIG_XP_SITES, false, false>([&](long s) -> uint32_t { return keys[s]; }, table, n, rho, sh, gamma_hint, delta);
 #else
-    exact_select_par_impl<4, 4, false, true>([&](long s) -> uint32_t { return keys[s]; }, table, n, rho, sh, gamma_hint, delta);
+    exact_select_par_impl<KMC_BIG_WAVES, KMC_BIG_XP_SITES, false, true>([&](long s) -> uint32_t { return keys[s]; }, table, n, rho, sh, gamma_hint, delta);
 #endif
+}
+
+// The same replay from the per-site words and the palette in LDS (SITEW instances)
+__device__ __noinline__ void exact_select_big_sw(const LatWP* __restrict__ sw, const double* pal, int n, double rho, BigXpShared* sh,
+                                                 double gamma_hint, double delta)
+{
+    static_assert(sizeof(XpSiteWord) == sizeof(LatWP), "same words");
+    XpRowsPalette rows = {reinterpret_cast<const XpSiteWord*>(sw), (const __attribute__((address_space(3))) double*)pal};
+    exact_select_rows_impl<KMC_BIG_WAVES, KMC_BIG_XP_SITES, false, true>(rows, n, rho, sh, gamma_hint, delta);
 }
 
 // NSLOTS = L1 blocks a window row can touch: 2 when ny is a multiple of 8 (the third slot's code is then gone, with the
 // uniform branches round it -- a taken branch costs this kernel's lone wave ~27 cycles), else 3
-template <bool COMPACT, int NSLOTS>
+//
+// SITEW (round 3; rows of up to 1024 sites, tables of up to 1024 distinct rates): the selection makes TWO dependent trips to
+// global memory instead of four.  (1) The row's <= 128 L1 sums are read at once, two per lane, and one wave scan picks the
+// block: the L2 level is kept for the climb only.  (2) Every site carries SW[site] = {W, the six rates of its (stale) key as
+// 10-bit indices into a palette of the table's distinct values}, the palette (8 KB) lives in LDS: the entry pick reads the
+// block's eight words and looks the 48 rates up in LDS, where it used to read the keys and then gather table rows.  The window
+// refresh gathers WP[new key] (16 B, the trip the W gather made anyway) and stores it to SW; the sites of a touched block
+// outside the window bring their W from SW, not from a second gather behind their keys.
+template <bool COMPACT, int NSLOTS, bool SITEW = false>
 __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -132,10 +170,11 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     uint32_t* bm = reinterpret_cast<uint32_t*>(smem);                      // [(ny + 4)][cw]
     const size_t bm_bytes = (((size_t)(ny + 4) * cw * 4) + 15) & ~(size_t)15;
     BigCtrl* ctl = reinterpret_cast<BigCtrl*>(smem + bm_bytes);
-    ExactParShared* xp = reinterpret_cast<ExactParShared*>(smem + bm_bytes + 256);
-    static_assert(sizeof(BigCtrl) <= 256, "ctrl block");
-    double* rowsum = reinterpret_cast<double*>(smem + bm_bytes + 256 + ((sizeof(ExactParShared) + 15) & ~(size_t)15));   // [nr1 * 8]
+    BigXpShared* xp = reinterpret_cast<BigXpShared*>(smem + bm_bytes + KMC_BIG_CTRL_BYTES);
+    static_assert(sizeof(BigCtrl) <= KMC_BIG_CTRL_BYTES, "ctrl block");
+    double* rowsum = reinterpret_cast<double*>(smem + bm_bytes + KMC_BIG_CTRL_BYTES + ((sizeof(BigXpShared) + 15) & ~(size_t)15));   // [nr1 * 8]
     double* R1 = rowsum + (size_t)g.nr1 * 8;                                                                             // [nr2 * 8]
+    double* PAL = R1 + (size_t)g.nr2 * 8 + 8;           // SITEW: [LAT_PAL_MAX], behind the 64 bytes of flush-only accumulators
 
     // (readfirstlane: the wave index is wave-uniform, which the compiler cannot see in tid >> 6 -- with it the hop loop's
     // control flow is scalar branches and its uniform values stay scalar)
@@ -161,6 +200,19 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     const unsigned char* wsum_b = reinterpret_cast<const unsigned char*>(wsum);
     auto ld_w = [&](uint32_t k) -> double { asm("" : "+v"(k)); return *reinterpret_cast<const double*>(wsum_b + (k << 3)); };
     auto ld_k = [&](uint32_t s) -> uint32_t { asm("" : "+v"(s)); return *reinterpret_cast<const uint32_t*>(keys_b + (s << 2)); };
+    LatWP* sw_g = SITEW ? p.sw + (size_t)r * n : nullptr;
+    const unsigned char* sw_b = reinterpret_cast<const unsigned char*>(sw_g);
+    const unsigned char* wp_b = reinterpret_cast<const unsigned char*>(p.wp);
+    auto ld_sw_w = [&](uint32_t s) -> double { asm("" : "+v"(s)); return *reinterpret_cast<const double*>(sw_b + (s << 4)); };
+    auto ld_sw_rp = [&](uint32_t s) -> uint2 { asm("" : "+v"(s)); return *reinterpret_cast<const uint2*>(sw_b + (s << 4) + 8); };
+    // WP[key], zeros for a vacant site (the palette table has the 2^18 rows of real keys only)
+    auto ld_wp = [&](uint32_t k) -> LatWP {
+        uint32_t kc = k > 0x3FFFFu ? 0u : k;
+        asm("" : "+v"(kc));
+        LatWP v = *reinterpret_cast<const LatWP*>(wp_b + (kc << 4));
+        if (k > 0x3FFFFu) { v.w = 0.0; v.rp = 0ull; }
+        return v;
+    };
 
     // bit (row rr, column cc) with rr in [-2, nx + 1], cc in [-2, ny + 1]
     auto bm_word = [&](int rr, int cc) -> int { return (cc + 2) * cw + ((rr + 2) >> 5); };
@@ -193,10 +245,18 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int j = blk * 8 + e;
-            w[e] = j < ny ? wsum[wkey(keys_g[(size_t)row * ny + j])] : 0.0;
+            if (SITEW) {
+                LatWP v; v.w = 0.0; v.rp = 0ull;
+                if (j < ny) { v = ld_wp(keys_g[(size_t)row * ny + j]); sw_g[(size_t)row * ny + j] = v; }
+                w[e] = v.w;
+            } else {
+                w[e] = j < ny ? wsum[wkey(keys_g[(size_t)row * ny + j])] : 0.0;
+            }
         }
         L1[(size_t)row * g.S1 + blk] = row_sum8(w);
     }
+    if (SITEW)
+        for (int k = tid; k < LAT_PAL_MAX; k += KMC_BIG_THREADS) PAL[k] = p.pal[k];
     __syncthreads();
     for (long q = tid; q < (long)nx * (g.S1 >> 3); q += KMC_BIG_THREADS) {
         const int row = (int)(q / (g.S1 >> 3)), b = (int)(q % (g.S1 >> 3));
@@ -235,6 +295,10 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
     const int ent_site = lane < 48 ? (lane * 43) >> 8 : 0;
     const int ent_dir = lane < 48 ? lane - 6 * ent_site : 0;
     const uint32_t ent_off = COMPACT ? (uint32_t)ent_dir * (KMC_COMPACT_ROWS * 8u) : (uint32_t)ent_dir * 8u;
+    // SITEW: direction d's palette index is bits 10 d .. 10 d + 9 of the 60-bit word: from the low dword (d = 3 straddles: a
+    // funnel shift) or from the high one
+    const bool ent_hi = ent_dir >= 4;
+    const uint32_t ent_sh = ent_hi ? 10u * (uint32_t)ent_dir - 32u : 10u * (uint32_t)ent_dir;
     uint32_t cf_st[5], cf_ln[5], cf_sh[5];
     {
         uint32_t m = compact_mask(ent_dir), o = 0;
@@ -284,8 +348,12 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
             while ((sq = *vseq) == seen) __builtin_amdgcn_s_sleep(16);
             seen = sq;
             if (*vstop) break;
-            exact_select_big(keys_g, BP->table, n, *(volatile double*)&ctl->rho, xp,
-                             BIG_XP_SHORT ? *(volatile double*)&ctl->gam : 0.0, BIG_XP_DELTA);
+            if (SITEW)
+                exact_select_big_sw(sw_g, PAL, n, *(volatile double*)&ctl->rho, xp,
+                                    BIG_XP_SHORT ? *(volatile double*)&ctl->gam : 0.0, BIG_XP_DELTA);
+            else
+                exact_select_big(keys_g, BP->table, n, *(volatile double*)&ctl->rho, xp,
+                                 BIG_XP_SHORT ? *(volatile double*)&ctl->gam : 0.0, BIG_XP_DELTA);
         }
     }
     double rho_v = 0.5, u_v = 1.0, gam_v = 1.0, pn_v = 1.0;
@@ -350,26 +418,52 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
                 i = g2 * 64 + q;
                 if (i >= nx) { ok = false; i = 0; }
             }
-            int b2;
-            {
-                const double l2_v = ld_h(oL2 + (uint32_t)i * (uint32_t)g.S2 + (uint32_t)(lane < g.S2 ? lane : g.S2 - 1));
-                const double sc = wave_scan_incl(lane < g.S2 ? l2_v : 0.0);
+            int b1;
+            if (SITEW) {
+                // the row's L1 sums, two per lane (S1 <= 128, its pads are zeros): one trip, one scan, and the pair's own pick
+                const int half = g.S1 >> 1;
+                uint32_t ho = (oL1 + (uint32_t)i * (uint32_t)g.S1 + 2u * (uint32_t)(lane < half ? lane : half - 1)) << 3;
+                asm("" : "+v"(ho));
+                double2 lp = *reinterpret_cast<const double2*>(hier_b + ho);
+                if (lane >= half) lp = make_double2(0.0, 0.0);
+                const double sc = wave_scan_incl(lp.x + lp.y);
                 const double bp = base + sc;
                 const double bpe = base + dpp_f64<0x138, 0xF>(sc);
+                const double a0 = bpe + lp.x;
+                const bool first = a0 >= t;
+                const double base_l = first ? bpe : a0;
                 const unsigned long long mb = ballot64(bp >= t);
                 ok = ok && mb != 0ull;
-                b2 = (__ffsll((long long)mb) - 1) & 63;
-                base = readlane_f64(bpe, b2);
-                if (b2 >= (g.S1 >> 3)) { ok = false; b2 = 0; }
+                const int q = (__ffsll((long long)mb) - 1) & 63;
+                b1 = 2 * q + (int)(((ballot64(first) >> q) & 1ull) ^ 1ull);
+                base = readlane_f64(base_l, q);
+            } else {
+                int b2;
+                {
+                    const double l2_v = ld_h(oL2 + (uint32_t)i * (uint32_t)g.S2 + (uint32_t)(lane < g.S2 ? lane : g.S2 - 1));
+                    const double sc = wave_scan_incl(lane < g.S2 ? l2_v : 0.0);
+                    const double bp = base + sc;
+                    const double bpe = base + dpp_f64<0x138, 0xF>(sc);
+                    const unsigned long long mb = ballot64(bp >= t);
+                    ok = ok && mb != 0ull;
+                    b2 = (__ffsll((long long)mb) - 1) & 63;
+                    base = readlane_f64(bpe, b2);
+                    if (b2 >= (g.S1 >> 3)) { ok = false; b2 = 0; }
+                }
+                b1 = b2 * 8 + descend(oL1 + (uint32_t)i * (uint32_t)g.S1 + (uint32_t)b2 * 8u, t, base, ok);
             }
-            int b1 = b2 * 8 + descend(oL1 + (uint32_t)i * (uint32_t)g.S1 + (uint32_t)b2 * 8u, t, base, ok);
             if (b1 >= g.nb1) { ok = false; b1 = 0; }
             KMC_STAMP(1);
             // ---- entry: 8 sites x 6 directions on 48 lanes ---------------------------------
             const int ej = b1 * 8 + ent_site;
+            double rate;
+            if (SITEW) {
+                const uint2 rp = ld_sw_rp((uint32_t)i * (uint32_t)ny + (uint32_t)(ej < ny ? ej : ny - 1));
+                const uint32_t pi = __builtin_amdgcn_alignbit(ent_hi ? 0u : rp.y, ent_hi ? rp.y : rp.x, ent_sh) & 1023u;
+                rate = PAL[(ej < ny && lane < 48) ? pi : 0u];             // palette[0] = 0.0
+            } else {
             const uint32_t ek_v = wkey(ld_k((uint32_t)i * (uint32_t)ny + (uint32_t)(ej < ny ? ej : ny - 1)));
             const uint32_t ek = ej < ny ? ek_v : KMC_BIG_VAC;
-            double rate;
             if (COMPACT) {
                 uint32_t ci = __builtin_amdgcn_ubfe(ek, cf_st[0], cf_ln[0]);
 #pragma unroll
@@ -381,6 +475,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
                 uint32_t ro = ek * 48u + ent_off;
                 asm("" : "+v"(ro));
                 rate = *reinterpret_cast<const double*>(table_b + ro);
+            }
             }
             const double esc = wave_scan_incl(rate);
             const double ap = base + esc;
@@ -445,6 +540,7 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         // ---- reads that do not depend on the update: old keys of the blocks' sites, and the
         // children of every tree node the window will change
         uint32_t kold[3];
+        double wold[3];                                      // SITEW: the W of the blocks' sites as they stand
         double c1[3], c2[3];
         // this lane's row in each array (24-bit multiplies: rows and strides are far below 2^24)
         const uint32_t si_ny = __umul24((uint32_t)si, (uint32_t)ny);
@@ -453,7 +549,12 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const int cj = bs[q] * 8 + grp_c;
-            if (q < nslots) {
+            wold[q] = 0.0;
+            if (q < nslots && SITEW) {
+                const double wv_ = ld_sw_w(si_ny + (uint32_t)(cj < ny ? cj : ny - 1));
+                wold[q] = cj < ny ? wv_ : 0.0;
+                kold[q] = KMC_VACANT;
+            } else if (q < nslots) {
                 const uint32_t kv = ld_k(si_ny + (uint32_t)(cj < ny ? cj : ny - 1));
                 kold[q] = cj < ny ? kv : KMC_VACANT;
             } else kold[q] = KMC_VACANT;
@@ -513,8 +614,13 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
                 uint32_t ks = si_ny + (uint32_t)sj;
                 asm("" : "+v"(ks));
                 *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(keys_g) + (ks << 2)) = knew;
+                if (SITEW) {
+                    const LatWP v = ld_wp(knew);
+                    *reinterpret_cast<LatWP*>(reinterpret_cast<unsigned char*>(sw_g) + (ks << 4)) = v;
+                    ctl->wscr[grp_a * 8 + grp_c] = v.w;
+                }
             }
-            ctl->kscr[grp_a * 8 + grp_c] = knew;
+            if (!SITEW) ctl->kscr[grp_a * 8 + grp_c] = knew;
         }
         wave_fence();
         KMC_STAMP(4);
@@ -526,9 +632,15 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
                 const int cj = bs[q] * 8 + grp_c;
                 int wc = cj - j_lo;
                 if (wc < 0) wc += ny;
-                const uint32_t kw = ctl->kscr[(act ? grp_a : 0) * 8 + (wc & 7)];
-                const uint32_t k = (cj < ny && wc < n_j) ? kw : kold[q];
-                const double wv_ = ld_w(wkey(k));            // a lane of an idle group reads row i_lo's keys: valid, unused
+                double wv_;
+                if (SITEW) {
+                    const double ww = ctl->wscr[(act ? grp_a : 0) * 8 + (wc & 7)];
+                    wv_ = (cj < ny && wc < n_j) ? ww : wold[q];
+                } else {
+                    const uint32_t kw = ctl->kscr[(act ? grp_a : 0) * 8 + (wc & 7)];
+                    const uint32_t k = (cj < ny && wc < n_j) ? kw : kold[q];
+                    wv_ = ld_w(wkey(k));                     // a lane of an idle group reads row i_lo's keys: valid, unused
+                }
                 wq[q] = act ? wv_ : 0.0;
             }
         }
@@ -664,7 +776,8 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
         __threadfence_block();
         if (lane == 0) { *(volatile double*)&ctl->rho = rho; *(volatile double*)&ctl->gam = gamma; *(volatile int*)&ctl->seq = ++seq_sent; }
         else ++seq_sent;
-        exact_select_big(keys_g, BP->table, n, rho, xp, BIG_XP_SHORT ? gamma : 0.0, BIG_XP_DELTA);
+        if (SITEW) exact_select_big_sw(sw_g, PAL, n, rho, xp, BIG_XP_SHORT ? gamma : 0.0, BIG_XP_DELTA);
+        else exact_select_big(keys_g, BP->table, n, rho, xp, BIG_XP_SHORT ? gamma : 0.0, BIG_XP_DELTA);
         ++n_exact;
         if (!(xp->gamma > 0.0)) { status = 2; break; }
         if (xp->idx >= 6LL * n) { status = 1; break; }

@@ -561,10 +561,11 @@ def test_errors_are_loud(kmc, tables):
     (130, 70, 1, 20, 100, 'hex_ref', 2, 3e9),
     (300, 260, 1, 100, 500, 'hex_ref', False, 2e6),
 ], ids=lambda c: '%dx%d-%s%s-m%g' % (c[0], c[1], c[5], {0: '', 1: '-exact', 2: '-exactshort'}[int(c[6])], c[7]))
-@pytest.mark.parametrize('kernel', ['big', 'global'])
+@pytest.mark.parametrize('kernel', ['big', 'big-tree', 'global'])
 def test_global_memory_kernel_vs_oracle(kmc, tables, dense, cfg, kernel):
-    """Lattices beyond 64 x 64: hop_big_kernel (sum tree in L2, bitmaps in LDS) and the older
-    hop_global_kernel (kept for lattices whose bitmaps do not fit LDS), both against the oracle."""
+    """Lattices beyond 64 x 64: hop_big_kernel (sum tree in L2, bitmaps in LDS; 'big' = with the per-site words and the
+    palette of round 3, 'big-tree' = without) and the older hop_global_kernel (kept for lattices whose bitmaps do not
+    fit LDS), all against the oracle."""
     nx, ny, R, hp, hs, mode, force, mscale = cfg
     rs = np.random.RandomState(nx + ny)
     conc = np.linspace(0.3, 0.7, R)
@@ -573,7 +574,8 @@ def test_global_memory_kernel_vs_oracle(kmc, tables, dense, cfg, kernel):
     d_sim = rs.rand(R, hs, 2)
     with make_engine(kmc, tables, R, nx, ny, mode) as eng:
         assert not eng.uses_lds_path
-        eng.set_hop_kernel(generic=(kernel == 'global'))
+        eng.set_hop_kernel(which={'big': 0, 'big-tree': 2, 'global': 1}[kernel])
+        assert eng.hop_kernel_name == {'big': 'hop_big_kernel<site words>', 'big-tree': 'hop_big_kernel', 'global': 'hop_global_kernel'}[kernel]
         eng.set_debug(force_exact=force, margin_scale=mscale)
         eng.set_lattice(occ)
         eng.rates_full()
@@ -627,18 +629,22 @@ def test_exact_short_form_equals_long_form(kmc, tables, nx, ny, table, hops, gen
             assert np.array_equal(a, b)
 
 
-def test_large_lattice_1024(kmc, tables, dense):
+@pytest.mark.parametrize('which', [0, 2], ids=['site-words', 'tree'])
+def test_large_lattice_1024(kmc, tables, dense, which):
     """BASELINE config 4: one 1024 x 1024 lattice.  Hop-for-hop against the C oracle
-    on a short run, then size-independent invariants on a longer Philox run."""
+    over 2 400 hops (the oracle's literal cumsum over 6.3 M entries per hop: ~20 s), then size-independent invariants
+    on a longer Philox run.  Both forms of hop_big_kernel."""
     nx = 1024
+    H = 2400 if which == 0 else 300
     rs = np.random.RandomState(1024)
     occ = (rs.rand(1, nx, nx) < 0.5).astype(np.int8)
-    d_sim = rs.rand(1, 150, 2)
+    d_sim = rs.rand(1, H, 2)
     with make_engine(kmc, tables, 1, nx) as eng:
+        eng.set_hop_kernel(which=which)
         eng.set_lattice(occ)
         eng.rates_full()
         eng.init_displacements()
-        idx = eng.run(150, presim=False, draws=d_sim, want_trace=True)
+        idx = eng.run(H, presim=False, draws=d_sim, want_trace=True)
         rep = CO.Replica(occ[0], dense)
         rep.init_tags()
         _, ref_idx, _ = rep.run(d_sim[0], False)
@@ -655,8 +661,8 @@ def test_large_lattice_1024(kmc, tables, dense):
         tags = eng.get_displacements()[0]
         assert int((tags[..., 0] >= 0).sum()) == n_li and np.array_equal(tags[..., 0] >= 0, lat == 1)
         st = eng.status()
-        assert st['status'][0] == 0 and st['hops_done'][0] == 20150
-        assert eng.scalars()['hist'][0].sum() == 20150
+        assert st['status'][0] == 0 and st['hops_done'][0] == 20000 + H
+        assert eng.scalars()['hist'][0].sum() == 20000 + H
         keys = eng.get_keys()[0]
         fresh = O.all_keys(lat)
         assert np.array_equal(keys == 0xFFFFFFFF, fresh == 0xFFFFFFFF)      # vacancy pattern always fresh
