@@ -349,8 +349,7 @@ def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red
     # equilibrate a little (presimulation mode), then switch the observables on
     eng.run(hops_per_step, presim=True, seed=SEED)
     eng.init_displacements()
-    for _ in range(args.warmup):
-        eng.run(hops_per_step, presim=False, seed=SEED)
+    eng.run(hops_per_step, presim=False, seed=SEED)
     eng.diffusion(CONC)              # warm-up of the exchange step too (first call loads its kernel)
     rccl = None
     if args.collective == 'rccl' and dist is not None:
@@ -360,6 +359,12 @@ def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red
             dist.broadcast_object_list(box, src=0, device=red_dev)
             rccl = (eng, eng.comm_create(box[0], dist.get_world_size(), dist.get_rank()))
     ensemble.all_reduce_acc(np.zeros((1, len(ensemble.ACC_FIELDS))), red_dev, rccl)   # ... and of the collective (RCCL set-up)
+    # the W warm-up steps come LAST, straight in front of the timed ones (no idle GPU between them and the timed region).
+    # A run of few steps still reads lower than a long one -- 20 steps 2.33e9, 2000 steps 2.41e9 hops/s -- because the first
+    # launch's prologue and the last one's tail are not hidden under a neighbour (one step alone takes 4.1 ms, back to back
+    # 3.48) and the exchange step (0.5 ms, scripts/time_exchange.py) is shared by fewer steps.
+    for _ in range(args.warmup):
+        eng.run(hops_per_step, presim=False, seed=SEED)
     eng.sync()
 
     def barrier():
@@ -422,10 +427,11 @@ def measure_other(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torc
     eng.rates_full()
     eng.run_counts(hops_vec, presim=True, seed=SEED)
     eng.init_displacements()
-    for _ in range(args.warmup):
-        eng.run_counts(hops_vec, presim=False, seed=SEED)
+    eng.run_counts(hops_vec, presim=False, seed=SEED)
     eng.diffusion(conc)
     ensemble.all_reduce_acc(np.zeros((1, len(ensemble.ACC_FIELDS))), red_dev)
+    for _ in range(args.warmup):         # last, straight in front of the timed steps (see measure())
+        eng.run_counts(hops_vec, presim=False, seed=SEED)
     eng.sync()
 
     def barrier():
