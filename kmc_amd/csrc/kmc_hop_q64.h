@@ -315,10 +315,20 @@ void hop_q64_kernel(HopParams p)
     bool need_exact = false;
     int done = 0;
     const int wave_slot = kmc_wave_slot();
+    // Per-replica hop counts (kmc_run_counts: the concentration sweep, every replica its own int(n x) hops a step): the launch
+    // lasts as long as its longest replica, so a wave's issue priority is the quarter of the longest run it still has to do
+    // -- the long replicas are served first while the short ones, which have the time, wait: BASELINE config 3 (9 x 512 replicas,
+    // x = 0.1 ... 0.9) 5.81 -> 5.45 ms per step (profiles/r3k_c3_priority.txt; classes by the replica's whole run instead of what
+    // is left of it measure the same)
+    const bool ragged = QP->n_hops_r != nullptr;
+    const long long run_quarter = (QP->n_hops + 3) >> 2;
     for (long long h0 = 0; h0 < my_hops && status == 0; h0 += done) {
         const int cnt = (int)((my_hops - h0) < KMC_WAVE ? (my_hops - h0) : KMC_WAVE);
         // priority = (slot on the SIMD - chunks done) mod 4: see kmc_rotate_priority (kmc_hop_lds.h)
-        kmc_rotate_priority(wave_slot - (int)(h0 >> 6));
+        if (ragged) {
+            const long long rem = my_hops - h0;
+            kmc_rotate_priority((rem > run_quarter) + (rem > 2 * run_quarter) + (rem > 3 * run_quarter));
+        } else kmc_rotate_priority(wave_slot - (int)(h0 >> 6));
         // ---- uniforms for the next 64 hops, one hop per lane --------------
         // (the clock's draw u is needed only at the flush and is produced again there: two registers
         // fewer across the hop loop, which runs at the 128-register limit of 4 waves per SIMD)
