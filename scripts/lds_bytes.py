@@ -17,9 +17,12 @@ BYTES = {'ds_read_b32': 4, 'ds_read_b64': 8, 'ds_read_b96': 12, 'ds_read_b128': 
          'ds_bpermute_b32': 4, 'ds_permute_b32': 4, 'ds_swizzle_b32': 4}                     # crossbar only, listed apart
 KERNELS = {'hop_q64_kernel': '_ZN3kmc14hop_q64_kernelILb1ELb0EEEvNS_9HopParamsE',
            'hop_q64_kernel<any>': '_ZN3kmc14hop_q64_kernelILb1ELb1EEEvNS_9HopParamsE',
-           'hop_lat_kernel': '_ZN3kmc14hop_lat_kernelILb0ELb1EEEvNS_9LatParamsE',
-           'hop_lat_kernel<any>': '_ZN3kmc14hop_lat_kernelILb1ELb1EEEvNS_9LatParamsE',
-           'hop_big_kernel': '_ZN3kmc14hop_big_kernelILb1ELi2EEEvNS_12HopBigParamsE'}
+           # <ANY, classes, two per CU>: 64 x 64 and 30 x 30 both take the class-mapped re-sum (lat_cls_ok)
+           'hop_lat_kernel': '_ZN3kmc14hop_lat_kernelILb0ELb1ELb0EEEvNS_9LatParamsE',
+           'hop_lat_kernel<any>': '_ZN3kmc14hop_lat_kernelILb1ELb1ELb0EEEvNS_9LatParamsE',
+           'hop_lat_kernel<2 per CU>': '_ZN3kmc14hop_lat_kernelILb0ELb1ELb1EEEvNS_9LatParamsE',
+           'hop_big_kernel<site words>': '_ZN3kmc14hop_big_kernelILb0ELi2ELb1EEEvNS_12HopBigParamsE',
+           'hop_big_kernel': '_ZN3kmc14hop_big_kernelILb1ELi2ELb0EEEvNS_12HopBigParamsE'}
 asm = '/tmp/kmc_lds_bytes.s'
 flags = [f for f in build.FLAGS if f not in ('-fPIC', '-shared')]
 subprocess.check_call([build.hipcc()] + flags + ['--cuda-device-only', '-S', '-o', asm, build.SRC], stderr=subprocess.DEVNULL)
