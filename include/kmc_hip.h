@@ -210,7 +210,10 @@ int kmc_table_is_compact(kmc_ctx* ctx);
  * the default is 3; 4 = that layout for lattices of 8 ... 64 rows and columns other than 64 x 64 (the default there);
  * 5 = the one-replica-per-CU kernel (kmc_hop_lat.h: rates, weights and fresh keys of every site in LDS), which is
  * also what 0 picks when the context holds at most 512 replicas of 8 ... 64 rows and columns (one replica per CU up to
- * 256, two beyond) and the rate table's distinct values fit its 1024-entry palette.  No counterpart in the reference. */
+ * 256, two beyond) and the rate table's distinct values fit its 1024-entry palette; 6 = its two-per-CU layout at any
+ * replica count.  Lattices beyond 64 x 64: 2 = the large-lattice kernel (kmc_hop_big.h) without the per-site rate words
+ * it uses by default where a row has at most 1024 sites and the table at most 1024 distinct rates.
+ * No counterpart in the reference. */
 int kmc_set_hop_kernel(kmc_ctx* ctx, int which);
 /* Name of the hop kernel the next kmc_run would launch ("hop_q64_kernel", "hop_lat_kernel<any>", ...): what
  * bench.py reports beside its timings.  A static string; never NULL.  No counterpart in the reference. */

@@ -292,7 +292,8 @@ class KMCEngine:
         64 x 64 replicas which=2 the 8-replicas-per-CU kernel (kmc_hop_lds64.h), which=3 the 16-per-CU one
         (kmc_hop_q64.h); which=4 the 16-per-CU layout for 8 ... 64 rows and columns other than 64 x 64; which=5 the
         one-replica-per-CU kernel (kmc_hop_lat.h), which=6 its two-per-CU layout at any replica count; which=0 the default (5 up to 512 replicas of 8 ... 64 rows and
-        columns, else 3 at 64 x 64, 4 where it applies)."""
+        columns, else 3 at 64 x 64, 4 where it applies).  Lattices beyond 64 x 64: which=1 the global-memory kernel,
+        which=2 the large-lattice kernel without its per-site rate words (the round-2 form)."""
         self._chk(self._lib.kmc_set_hop_kernel(self._ctx, int(which) if which is not None else int(bool(generic))))
 
     @property
