@@ -213,7 +213,9 @@ int kmc_table_is_compact(kmc_ctx* ctx);
  * 256, two beyond) and the rate table's distinct values fit its 1024-entry palette; 6 = its two-per-CU layout at any
  * replica count.  Lattices beyond 64 x 64: 2 = the large-lattice kernel (kmc_hop_big.h) without the per-site rate words
  * it uses by default where a row has at most 1024 sites and the table at most 1024 distinct rates.
- * No counterpart in the reference. */
+ * Kernels 3 ... 6 store a vacant site as the all-Li key 0x3FFFF, whose row is zero in every table that describes hops (all
+ * six end points occupied); a table whose row 0x3FFFF is not zero runs on the kernels that keep an explicit zero row (0 picks
+ * them by itself) and asking for 3 ... 6 returns KMC_ESTATE.  No counterpart in the reference. */
 int kmc_set_hop_kernel(kmc_ctx* ctx, int which);
 /* Name of the hop kernel the next kmc_run would launch ("hop_q64_kernel", "hop_lat_kernel<any>", ...): what
  * bench.py reports beside its timings.  A static string; never NULL.  No counterpart in the reference. */

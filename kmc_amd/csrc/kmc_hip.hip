@@ -47,6 +47,8 @@ struct kmc_ctx {
     // (kmc_set_hop_kernel(ctx, 5)), -1 = never.  pal_state: 0 = palette not built for the current table, 1 = built,
     // -1 = the table holds more than LAT_PAL_MAX distinct rates.
     bool lat_ok, lat_pk; int lat_mode, pal_state, n_pal;
+    int which_req;         // what kmc_set_hop_kernel asked for
+    bool vac_row_ok;       // the table's all-Li row 0x3FFFF is zero (true of every table that describes hops): see apply_hop_kernel_choice
     LatWP* wp;             // [2^18] {W, palette indices} (lazy)
     double* pal;           // [LAT_PAL_MAX]
     bool big_ok, use_big;  // larger lattices whose bitmaps fit LDS: kmc_hop_big.h (else kmc_hop_global.h)
@@ -897,6 +899,7 @@ int kmc_create(kmc_ctx** out, int device, int n_replicas, int nx, int ny, int wi
     c->qany = c->qany_ok;
     if (c->lds64 || c->qany_ok) CREATE_CHK(hipMalloc(&c->xscratch, (size_t)c->R * Q64_XSCRATCH));
     c->lat_ok = c->lds64 || c->qany_ok;
+    c->vac_row_ok = true;
     if (c->lat_ok) {
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_LDS_BYTES));
         CREATE_CHK(hipFuncSetAttribute((const void*)hop_lat_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LAT_LDS_BYTES));
@@ -1046,12 +1049,12 @@ int kmc_lds_bytes(kmc_ctx* c)
 // which = 0: the default kernel for the lattice size and replica count; 1: the generic kernel (any size);
 // 2 / 3: for 64 x 64 replicas, the 8-replicas-per-CU kernel (kmc_hop_lds64.h) / the 16-per-CU one (kmc_hop_q64.h);
 // 4: the 16-per-CU layout for lattices of 8 .. 64 rows and columns other than 64 x 64 (the default there)
-int kmc_set_hop_kernel(kmc_ctx* c, int which)
+// (hop_q64_kernel and hop_lat_kernel store a vacant site as the all-Li key 0x3FFFF, whose table row is zero for every table
+// that describes hops -- all six end points are occupied.  A table whose row 0x3FFFF is NOT zero, vac_row_ok == false, takes
+// the kernels that keep the explicit zero row 0x7FFFF instead; asking for the others by number is then an error.)
+static void apply_hop_kernel_choice(kmc_ctx* c)
 {
-    CTXCHK(c);
-    if (which < 0 || which > 6) return fail(c, KMC_EINVAL, "kmc_set_hop_kernel: which must be 0 ... 6");
-    if (which >= 5 && !c->lat_ok)
-        return fail(c, KMC_EINVAL, "kmc_set_hop_kernel: the one-replica-per-CU kernel takes lattices of 8 ... 64 rows and columns");
+    int which = c->which_req;
     c->lat_mode = which >= 5 ? 1 : (which == 0 ? 0 : -1);
     c->lat_pk = which == 6;                    // its two-per-CU layout whatever the replica count (tests)
     if (which >= 5) which = 0;
@@ -1060,6 +1063,34 @@ int kmc_set_hop_kernel(kmc_ctx* c, int which)
     c->q64 = c->lds64 && (which == 3 || (which == 0 && c->q64_auto));
     c->use_big = c->big_ok && which != 1;
     c->big_tree = which == 2;                  // lattices beyond 64 x 64: hop_big_kernel without the per-site words
+    if (!c->vac_row_ok) { c->qany = false; c->q64 = false; c->lat_mode = -1; }
+}
+
+int kmc_set_hop_kernel(kmc_ctx* c, int which)
+{
+    CTXCHK(c);
+    if (which < 0 || which > 6) return fail(c, KMC_EINVAL, "kmc_set_hop_kernel: which must be 0 ... 6");
+    if (which >= 5 && !c->lat_ok)
+        return fail(c, KMC_EINVAL, "kmc_set_hop_kernel: the one-replica-per-CU kernel takes lattices of 8 ... 64 rows and columns");
+    if (which >= 3 && c->lds_path && !c->vac_row_ok)
+        return fail(c, KMC_ESTATE, "kmc_set_hop_kernel: the rate table's all-Li row (key 0x3FFFF) is not zero, which the kernels %d "
+                    "stands for take for granted (they store a vacant site as that key)", which);
+    c->which_req = which;
+    apply_hop_kernel_choice(c);
+    return KMC_OK;
+}
+
+// after a table has been set: is its all-Li row zero?
+static int check_vacant_row(kmc_ctx* c)
+{
+    double row[6];
+    HIPCHK(c, hipMemcpyAsync(row, c->table + (size_t)0x3FFFF * 6, sizeof(row), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    bool ok = true;
+    for (int d = 0; d < 6; ++d) ok = ok && row[d] == 0.0;
+    c->vac_row_ok = ok;
+    if (!ok && c->which_req >= 3) c->which_req = 0;      // the kernel asked for by number no longer applies
+    apply_hop_kernel_choice(c);
     return KMC_OK;
 }
 
@@ -1100,7 +1131,7 @@ static int build_compact(kmc_ctx* c)
     int bad = 0;
     HIPCHK(c, hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->have_compact = bad == 0;
+    c->have_compact = bad == 0 && c->vac_row_ok;        // (the compact paths read a vacant site's rates at the all-Li entry)
     return KMC_OK;
 }
 
@@ -1172,6 +1203,7 @@ int kmc_set_base_table(kmc_ctx* c, const double* base512, double dumbbell)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_table = true;
     c->pal_state = 0;
+    if (int rc = check_vacant_row(c)) return rc;
     return build_compact(c);
 }
 
@@ -1185,6 +1217,7 @@ int kmc_set_hex_table(kmc_ctx* c, const double* table)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_table = true;
     c->pal_state = 0;
+    if (int rc = check_vacant_row(c)) return rc;
     return build_compact(c);
 }
 

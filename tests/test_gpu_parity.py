@@ -602,6 +602,65 @@ def test_global_memory_kernel_vs_oracle(kmc, tables, dense, cfg, kernel):
         assert 0 < st['n_exact'].sum() < 0.5 * R * (hp + hs)
 
 
+def _random_hop_table(rs, all_li_row_zero=True):
+    """A dense table of ~10^6 distinct rates that still describes hops: the rate of a direction is zero where its end point is
+    occupied (key char 8, 4, 5, 9, 13, 12 for the six directions; char p is bit 17 - p)."""
+    t = np.exp(rs.uniform(-20.0, 0.0, size=(1 << 18, 6)))
+    keys = np.arange(1 << 18)
+    for d, p in enumerate((8, 4, 5, 9, 13, 12)):
+        t[((keys >> (17 - p)) & 1) == 1, d] = 0.0
+    assert not t[0x3FFFF].any()
+    if not all_li_row_zero:
+        t[0x3FFFF] = 1e-3                    # never selected at x ~ 0.5 (a site with 18 Li neighbours), but no longer "vacant"
+    return t
+
+
+@pytest.mark.parametrize('nx,ny,R,hp,hs,zero', [(64, 64, 3, 200, 600, True), (30, 30, 3, 200, 600, True), (70, 66, 2, 100, 400, True),
+                                               (6, 1100, 1, 100, 300, True), (64, 64, 2, 200, 400, False), (30, 30, 2, 200, 400, False),
+                                               (70, 66, 1, 100, 300, False)],
+                         ids=['64x64', '30x30', '70x66', '6x1100-rows-wider-than-the-pair-scan', '64x64-all-Li-row-not-zero',
+                              '30x30-all-Li-row-not-zero', '70x66-all-Li-row-not-zero'])
+def test_kernels_fall_back_when_their_table_forms_do_not_apply(kmc, tables, nx, ny, R, hp, hs, zero):
+    """hop_lat_kernel and hop_big_kernel's per-site words read rates through a palette of at most 1024 distinct values, the
+    latter scans a row's block sums two per lane (rows of at most 1024 sites), and hop_q64_kernel / hop_lat_kernel store a vacant
+    site as the all-Li key, whose row is zero in any table that describes hops.  A table of ~10^6 distinct rates (which does not
+    factor into the pair tables either: the dense gathers), a row of 1100 sites, and a table whose all-Li row is not zero must
+    each take the kernels that do not need the form, by themselves, hop for hop like the oracle; asking for the others by
+    number is an error."""
+    rs = np.random.RandomState(nx * 7 + ny + int(zero))
+    dense_t = O.build_hex_table(tables[0]['base512_normcons']) if ny > 1024 else _random_hop_table(rs, zero)
+    conc = np.linspace(0.4, 0.6, R)
+    occ = np.stack([(rs.rand(nx, ny) < c).astype(np.int8) for c in conc])
+    d_pre = np.stack([rs.rand(R, hp), np.ones((R, hp))], axis=-1)
+    d_sim = rs.rand(R, hs, 2)
+    with kmc.KMCEngine(R, nx, ny, window_mode='hex_ref') as eng:
+        eng.set_hex_table(dense_t)
+        eng.set_lattice(occ)
+        eng.rates_full()
+        i1 = eng.run(hp, presim=True, draws=d_pre, want_trace=True)
+        if zero:
+            assert eng.hop_kernel_name in ('hop_q64_kernel', 'hop_q64_kernel<any>', 'hop_big_kernel')
+        else:
+            assert eng.hop_kernel_name in ('hop_lds64_kernel', 'hop_lds_kernel', 'hop_big_kernel')
+        eng.init_displacements()
+        i2 = eng.run(hs, presim=False, draws=d_sim, want_trace=True)
+        got = np.concatenate([i1, i2], axis=1)
+        lat, tags, st = eng.get_lattice(), eng.get_reference_tags(), eng.status()
+        if eng.uses_lds_path and zero:
+            eng.set_hop_kernel(which=5)
+            with pytest.raises(kmc.KMCError, match='distinct rates'):
+                eng.run(10, presim=True, seed=1)
+        elif eng.uses_lds_path:
+            for which in (3, 4, 5):
+                with pytest.raises(kmc.KMCError, match='all-Li row'):
+                    eng.set_hop_kernel(which=which)
+    assert not st['status'].any()
+    for r in range(R):
+        rep, idx = _oracle_run(occ[r], dense_t, 'hex_ref', d_pre[r], d_sim[r], conc[r])
+        assert np.array_equal(got[r], idx), 'replica %d' % r
+        assert np.array_equal(lat[r], rep.occ) and np.array_equal(tags[r], rep.tags)
+
+
 @pytest.mark.parametrize('nx,ny,table,hops,generic', [(130, 70, 'normcons', 6000, False), (200, 136, 'master', 3000, False),
                                                       (130, 70, 'normcons', 3000, True), (90, 150, 'master', 2000, True)],
                          ids=['130x70-normcons', '200x136-master', '130x70-normcons-global', '90x150-master-global'])
