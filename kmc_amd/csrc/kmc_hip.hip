@@ -255,17 +255,16 @@ __global__ __launch_bounds__(512) void lce_rates_kernel(const double* __restrict
 }
 
 // ======================================================================
-// kernels: full rate fill (rows R1, R2) with LDS halo staging
+// kernels: full rate fill (rows R1, R2)
 // ======================================================================
-// One block = a TI x TJ tile of one replica.  The (TI+4) x (TJ+4) occupancy
-// halo (periodic wrap) is staged into LDS with coalesced byte-row reads, then
-// each thread builds the 18-bit keys of its sites from LDS and, if asked,
-// gathers the 48-byte table row into the rate matrix.
+// rates_full_kernel: the first version, kept for lattices under 5 rows or columns (the register kernels below need a 5-row
+// window that does not wrap onto itself).  One block = a TI x TJ tile of one replica.  The (TI+4) x (TJ+4) occupancy
+// halo (periodic wrap, true modulo) is staged into LDS with coalesced byte-row reads, then each thread builds the 18-bit
+// keys of its sites from LDS.
 #define RF_TI 16
 #define RF_TJ 64
 __global__ __launch_bounds__(256) void rates_full_kernel(const uint8_t* __restrict__ occ, int nx, int ny, int tiles_i,
-                                                          int tiles_j, const double* __restrict__ table,
-                                                          uint32_t* __restrict__ keys, double* __restrict__ P)
+                                                          int tiles_j, uint32_t* __restrict__ keys)
 {
     __shared__ uint8_t tile[(RF_TI + 4) * (RF_TJ + 4)];
     const int n = nx * ny;
@@ -295,15 +294,6 @@ __global__ __launch_bounds__(256) void rates_full_kernel(const uint8_t* __restri
                 key = (key << 1) | tile[(a + 2 + kNbI[p]) * (RF_TJ + 4) + (c + 2 + kNbJ[p])];
         }
         keys[s] = key;
-        if (P) {
-            double2 v0 = make_double2(0., 0.), v1 = v0, v2 = v0;
-            if (key != KMC_VACANT) {
-                const double2* t = reinterpret_cast<const double2*>(table + (size_t)key * 6);
-                v0 = t[0]; v1 = t[1]; v2 = t[2];
-            }
-            double2* out = reinterpret_cast<double2*>(P + s * 6);
-            out[0] = v0; out[1] = v1; out[2] = v2;
-        }
     }
 }
 
@@ -1291,9 +1281,9 @@ int kmc_fill_random(kmc_ctx* c, const double* conc, uint64_t seed)
 }
 
 // ---------------------------------------------------------------- rates
-static int launch_rates_full(kmc_ctx* c, double* P)
+static int launch_rates_full(kmc_ctx* c)
 {
-    if (!P && c->nx >= 5 && c->ny >= 5 && c->nx <= 64 && c->ny <= 64) {
+    if (c->nx >= 5 && c->ny >= 5 && c->nx <= 64 && c->ny <= 64) {
         if (c->nx == 64 && c->ny == 64)
             rates_cols_kernel<64><<<c->R, 64, 0, c->stream>>>(c->occ, c->R, c->nx, c->ny, c->keys);
         else {
@@ -1305,7 +1295,7 @@ static int launch_rates_full(kmc_ctx* c, double* P)
         HIPCHK(c, hipGetLastError());
         return KMC_OK;
     }
-    if (!P && c->nx >= 5 && c->ny >= 5) {
+    if (c->nx >= 5 && c->ny >= 5) {
         // tiles of 28 rows when that still gives the chip 32 waves per CU, else of 12
         const int tj = (c->ny + 63) / 64;
         const long long b28 = (long long)c->R * ((c->nx + 27) / 28) * tj, b12 = (long long)c->R * ((c->nx + 11) / 12) * tj;
@@ -1321,7 +1311,7 @@ static int launch_rates_full(kmc_ctx* c, double* P)
     const int ti = (c->nx + RF_TI - 1) / RF_TI, tj = (c->ny + RF_TJ - 1) / RF_TJ;
     const long long blocks = (long long)c->R * ti * tj;
     if (blocks > 0x7fffffffLL) return fail(c, KMC_EINVAL, "rates_full: grid too large");
-    rates_full_kernel<<<(unsigned)blocks, 256, 0, c->stream>>>(c->occ, c->nx, c->ny, ti, tj, c->table, c->keys, P);
+    rates_full_kernel<<<(unsigned)blocks, 256, 0, c->stream>>>(c->occ, c->nx, c->ny, ti, tj, c->keys);
     HIPCHK(c, hipGetLastError());
     return KMC_OK;
 }
@@ -1331,7 +1321,7 @@ int kmc_rates_full(kmc_ctx* c)
     CTXCHK(c);
     if (!c->have_table) return fail(c, KMC_ESTATE, "kmc_rates_full: set a rate table first");
     time_begin(c);
-    int rc = launch_rates_full(c, nullptr);
+    int rc = launch_rates_full(c);
     time_end(c);
     if (rc) return rc;
     c->have_keys = true;

@@ -462,20 +462,20 @@ __global__ __launch_bounds__(KMC_BIG_THREADS) void hop_big_kernel(HopBigParams p
                 const uint32_t pi = __builtin_amdgcn_alignbit(ent_hi ? 0u : rp.y, ent_hi ? rp.y : rp.x, ent_sh) & 1023u;
                 rate = PAL[(ej < ny && lane < 48) ? pi : 0u];             // palette[0] = 0.0
             } else {
-            const uint32_t ek_v = wkey(ld_k((uint32_t)i * (uint32_t)ny + (uint32_t)(ej < ny ? ej : ny - 1)));
-            const uint32_t ek = ej < ny ? ek_v : KMC_BIG_VAC;
-            if (COMPACT) {
-                uint32_t ci = __builtin_amdgcn_ubfe(ek, cf_st[0], cf_ln[0]);
+                const uint32_t ek_v = wkey(ld_k((uint32_t)i * (uint32_t)ny + (uint32_t)(ej < ny ? ej : ny - 1)));
+                const uint32_t ek = ej < ny ? ek_v : KMC_BIG_VAC;
+                if (COMPACT) {
+                    uint32_t ci = __builtin_amdgcn_ubfe(ek, cf_st[0], cf_ln[0]);
 #pragma unroll
-                for (int f = 1; f < 5; ++f) ci |= __builtin_amdgcn_ubfe(ek, cf_st[f], cf_ln[f]) << cf_sh[f];
-                uint32_t ro = (ci << 3) + ent_off;
-                asm("" : "+v"(ro));
-                rate = *reinterpret_cast<const double*>(tc_b + ro);
-            } else {
-                uint32_t ro = ek * 48u + ent_off;
-                asm("" : "+v"(ro));
-                rate = *reinterpret_cast<const double*>(table_b + ro);
-            }
+                    for (int f = 1; f < 5; ++f) ci |= __builtin_amdgcn_ubfe(ek, cf_st[f], cf_ln[f]) << cf_sh[f];
+                    uint32_t ro = (ci << 3) + ent_off;
+                    asm("" : "+v"(ro));
+                    rate = *reinterpret_cast<const double*>(tc_b + ro);
+                } else {
+                    uint32_t ro = ek * 48u + ent_off;
+                    asm("" : "+v"(ro));
+                    rate = *reinterpret_cast<const double*>(table_b + ro);
+                }
             }
             const double esc = wave_scan_incl(rate);
             const double ap = base + esc;
