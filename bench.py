@@ -14,8 +14,12 @@ keyed by the ensemble-wide replica id (one seed for all ranks: the ensemble does
   --scaling weak   (default) 4096 replicas PER GPU: rank r owns replicas [4096 r, 4096 (r + 1))
   --scaling strong 4096 replicas IN TOTAL (BASELINE config 5 as written): rank r owns [4096 r / N, 4096 (r + 1) / N)
 At N > 1 the line of the chosen scaling also carries the other one's numbers (`other_scaling`).
-One "step" = one reference KMC step = int(64*64*0.5) = 2048 hops in every replica (hex_LiCoO2_kmc.py:484),
-executed by one run of the fused hop kernel.  Replicas are independent, ranks share nothing on the data path;
+One "step" = one reference KMC step = int(64*64*0.5) = 2048 hops in every replica (hex_LiCoO2_kmc.py:484).
+Nothing happens on the host between the steps of a run (the reference's loop, :745-758, adds the step's clock to a
+total), so the K timed steps are executed in launches of up to 32 steps of the fused hop kernel, as the production
+driver (ensemble.run_ensemble) runs them; --launch-steps 1 gives one launch per step, the granularity of the drop-in
+kmc_step loop, which the line also reports (`per_step_launch_rank0`).  The results do not depend on the split.
+Replicas are independent, ranks share nothing on the data path;
 the single exchange is the all-reduce of the D* / D_J accumulators after the timed steps (inside the timed
 region), loops hex_LiCoO2_kmc.py:679-693.
 
@@ -242,7 +246,9 @@ def build_roofline(config, kernel, k_ms, step_hops, groups, replicas_per_launch,
             'frac': None, 'traffic': None, 'kernel': kernel, 'kernel_ms': k_ms, 'launches_per_step': groups,
             'hops_per_step_rank0': step_hops, 'waves_per_simd': waves_per_simd, 'simds_used': simds_used,
             'formula': 'achieved = SQ_ACTIVE_INST_VALU per hop (PMC, quad-cycles summed over waves) x hops per step / kernel_ms; '
-                       'peak = SIMDs holding a wave x 2.4 GHz / 4; kernel_ms = HIP-event span of the timed launches / steps (live)'}
+                       'peak = SIMDs holding a wave x 2.4 GHz / 4; kernel_ms = HIP-event span of the timed launches / steps in them (live); '
+                       'the counters are per hop, from a pass of one-step launches (a fused launch spares a prologue and a '
+                       'write-back per step: ~1 % fewer instructions per hop than counted)'}
     if launch_ms is not None:
         roof['launch_ms'] = launch_ms
     pj, why = load_pmc(config, kernel, replicas_per_launch)
@@ -359,12 +365,24 @@ def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red
             dist.broadcast_object_list(box, src=0, device=red_dev)
             rccl = (eng, eng.comm_create(box[0], dist.get_world_size(), dist.get_rank()))
     ensemble.all_reduce_acc(np.zeros((1, len(ensemble.ACC_FIELDS))), red_dev, rccl)   # ... and of the collective (RCCL set-up)
+    S = launch_steps(args)
+
+    def run_steps(k):
+        """k KMC steps (2048 hops per replica each) in launches of up to S steps: nothing on the host happens between the
+        steps of a run (the reference's loop, hex_LiCoO2_kmc.py:745-758, only adds the step's clock to a total), so the
+        production driver, ensemble.run_ensemble, puts them into one launch; the results do not depend on the split."""
+        sizes = []
+        while k > 0:
+            m = min(S, k)
+            eng.run(hops_per_step * m, presim=False, seed=SEED)
+            sizes.append(m)
+            k -= m
+        return sizes
     # the W warm-up steps come LAST, straight in front of the timed ones (no idle GPU between them and the timed region).
     # A run of few steps still reads lower than a long one -- 20 steps 2.33e9, 2000 steps 2.41e9 hops/s -- because the first
     # launch's prologue and the last one's tail are not hidden under a neighbour (one step alone takes 4.1 ms, back to back
     # 3.48) and the exchange step (0.5 ms, scripts/time_exchange.py) is shared by fewer steps.
-    for _ in range(args.warmup):
-        eng.run(hops_per_step, presim=False, seed=SEED)
+    run_steps(args.warmup)
     eng.sync()
 
     def barrier():
@@ -376,8 +394,7 @@ def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.run(hops_per_step, presim=False, seed=SEED)
+    sizes = run_steps(args.steps)
     # the one exchange step: D* / D_J accumulators of this rank's replicas
     ds, dj, _ = eng.diffusion(CONC)
     sc = eng.scalars()
@@ -395,23 +412,31 @@ def measure(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torch, red
     # launch.  A step may be several concurrent launches over disjoint replicas (kmc_set_launch_groups) and the
     # launches of consecutive steps overlap, so the GPU time per step is the span from the first kernel start of
     # the timed region (of its last 64 steps) to the last kernel end, divided by the steps in it.
-    n_span = min(args.steps, 64)
+    n_span = min(len(sizes), 64)                             # launches (of S steps each, the last one maybe shorter)
     ev = eng.run_kernel_times(64)[-n_span:]
     span_ms, groups = eng.run_span_ms(n_span)
-    out = dict(elapsed=elapsed, k_ms=span_ms / n_span, launch_ms=float(np.mean(ev)), groups=groups, R=R,
+    out = dict(elapsed=elapsed, k_ms=span_ms / sum(sizes[-n_span:]), launch_ms=float(np.mean(ev)), groups=groups, R=R, launch_steps=S,
                n_exact=int(st['n_exact'].sum()), stopped=int((st['status'] != 0).sum()),
                stats=ensemble.finalize(acc, [CONC])[0], fold_ms=fold_ms, rates_ms=rates_ms,
                hops_per_step=hops_per_step, base512=base512, kernel=eng.hop_kernel_name)
-    # For information (not `value`): the same kernel when a run is ONE launch of many KMC steps, as ensemble.run_ensemble
-    # and the sweep driver make them -- no prologue / write-back / tail per 2048 hops.  After everything that is reported.
-    # (--no-long-launch: the profile passes average their counters over the launches of ONE size)
-    out['long_launch'] = None
-    if not args.no_long_launch:
-        long_steps = 32
-        eng.run(hops_per_step * long_steps, presim=False, seed=SEED)
+    # For information (not `value`): the same steps as ONE LAUNCH PER KMC STEP, the granularity of the drop-in kmc_step loop
+    # (every launch pays a prologue, a write-back and the skew of its waves' ends: the slots of a launch group's early
+    # finishers idle until its last wave is done).  After everything that is reported.
+    # (--no-long-launch: the profile passes skip it)
+    out['per_step_launch'] = None
+    if not args.no_long_launch and S > 1:
+        n1 = 40
+        for _ in range(4):
+            eng.run(hops_per_step, presim=False, seed=SEED)
         eng.sync()
-        out['long_launch'] = dict(kmc_steps_per_launch=long_steps, kernel_ms=eng.last_kernel_ms(),
-                                  hops_per_s_this_rank=R * hops_per_step * long_steps / (eng.last_kernel_ms() * 1e-3))
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            eng.run(hops_per_step, presim=False, seed=SEED)
+        eng.sync()
+        w1 = time.perf_counter() - t1
+        span1, _ = eng.run_span_ms(n1)
+        out['per_step_launch'] = dict(kmc_steps=n1, ms_per_step=w1 / n1 * 1e3, kernel_ms_per_step=span1 / n1,
+                                      hops_per_s_this_rank=R * hops_per_step * n1 / w1)
     if rccl is not None:
         eng.comm_destroy(rccl[1])
     eng.close()
@@ -430,8 +455,17 @@ def measure_other(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torc
     eng.run_counts(hops_vec, presim=False, seed=SEED)
     eng.diffusion(conc)
     ensemble.all_reduce_acc(np.zeros((1, len(ensemble.ACC_FIELDS))), red_dev)
-    for _ in range(args.warmup):         # last, straight in front of the timed steps (see measure())
-        eng.run_counts(hops_vec, presim=False, seed=SEED)
+    S = launch_steps(args)
+
+    def run_steps(k):                    # k steps in launches of up to S (see measure())
+        sizes = []
+        while k > 0:
+            m = min(S, k)
+            eng.run_counts(hops_vec * m, presim=False, seed=SEED)
+            sizes.append(m)
+            k -= m
+        return sizes
+    run_steps(args.warmup)               # last, straight in front of the timed steps (see measure())
     eng.sync()
 
     def barrier():
@@ -443,8 +477,7 @@ def measure_other(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torc
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.run_counts(hops_vec, presim=False, seed=SEED)
+    sizes = run_steps(args.steps)
     ds, dj, _ = eng.diffusion(conc)
     sc, st = eng.scalars(), eng.status()
     point = ((offset + np.arange(R)) % len(cfg['conc'])).astype(np.int64)
@@ -456,9 +489,9 @@ def measure_other(kmc_amd, ensemble, np, args, R, offset, local_rank, dist, torc
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev if red_dev is not None else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    n_span = min(args.steps, 64)
+    n_span = min(len(sizes), 64)
     span_ms, groups = eng.run_span_ms(n_span)
-    out = dict(elapsed=elapsed, k_ms=span_ms / n_span, groups=groups, R=R, n_exact=int(st['n_exact'].sum()),
+    out = dict(elapsed=elapsed, k_ms=span_ms / sum(sizes[-n_span:]), groups=groups, R=R, launch_steps=S, n_exact=int(st['n_exact'].sum()),
                stopped=int((st['status'] != 0).sum()), stats=ensemble.finalize(acc, cfg['conc']), step_hops_rank=int(hops_vec.sum()),
                lds_bytes=eng.lds_bytes, lds_path=eng.uses_lds_path, kernel=eng.hop_kernel_name,
                uniform_hops=bool((hops_vec == hops_vec[0]).all()))
@@ -525,6 +558,11 @@ def d_star_check_run(kmc_amd, np, local_rank, base512, n_replicas=4, sim_steps=4
                     presim_hops=hops_per_step, sim_hops=hops_per_step * sim_steps)
 
 
+def launch_steps(args):
+    """KMC steps per launch of the timed run: --launch-steps, else as many as fit (up to 32)."""
+    return max(1, args.launch_steps if args.launch_steps else min(args.steps, 32))
+
+
 def occupancy_of(kernel, R):
     """(waves per SIMD, SIMDs that hold a wave) of a launch of R one-wave replicas of `kernel` on the 256 CUs."""
     if kernel.startswith('hop_big') or kernel.startswith('hop_global'):
@@ -555,8 +593,11 @@ def main():
                          '(an RCCL communicator of the engine\'s own, behind the C ABI)')
     ap.add_argument('--config', type=int, default=5, choices=(1, 2, 3, 4, 5),
                     help='BASELINE.json config to run: 5 (default) is the metric\'s workload; 1-4 are its parity-test cases')
+    ap.add_argument('--launch-steps', type=int, default=None,
+                    help='KMC steps per kernel launch (default: up to 32, as ensemble.run_ensemble runs them; 1 = one launch per '
+                         'step, the granularity of the drop-in kmc_step loop and of the counter passes)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-long-launch', action='store_true', help='skip the informational 32-step launch after the timed region')
+    ap.add_argument('--no-long-launch', action='store_true', help='skip the informational one-launch-per-step leg after the timed region')
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 200 if args.config == 4 else 2000
@@ -639,7 +680,7 @@ def main():
                 'scaling': 'strong' if cfg['R'] >= world else 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                 'config': {'workload': cfg['what'], 'replicas_total': cfg['R'] if cfg['R'] >= world else cfg['R'] * world,
                            'lattice': [cfg['n'], cfg['n']], 'concentrations': cfg['conc'], 'hops_per_step_all_replicas': hops_all, 'seed': SEED},
-                'roofline': roof, 'dropin': dropin,
+                'roofline': roof, 'dropin': dropin, 'launch_steps': mo['launch_steps'],
                 'kernel_hops_per_s': mo['step_hops_rank'] / (mo['k_ms'] * 1e-3), 'exact_path_hops': mo['n_exact'],
                 'stopped_replicas': mo['stopped'], 'd_star_by_concentration': [[r['concentration'], r['d_star'], r['error_star']] for r in mo['stats']]})
         return
@@ -676,8 +717,8 @@ def main():
         'ms_per_step': m['elapsed'] / args.steps * 1e3, 'higher_is_better': True, 'scaling': args.scaling,
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': '%d x 64x64 hex replicas %s (%s scaling; %d in total on %d GPU(s)), x=0.5, hex_ref window, 2048 hops/step '
-                               '(1 reference KMC step), Philox draws keyed by global replica id, normcons table'
-                               % (args.replicas, 'per GPU' if args.scaling == 'weak' else 'in total', args.scaling, total, world),
+                               '(1 reference KMC step; up to %d steps per kernel launch), Philox draws keyed by global replica id, normcons table'
+                               % (args.replicas, 'per GPU' if args.scaling == 'weak' else 'in total', args.scaling, total, world, m['launch_steps']),
                    'replicas_total': total, 'replicas_rank0': R, 'lattice': [N_SIDE, N_SIDE], 'concentration': CONC,
                    'hops_per_step': hops_per_step, 'seed': SEED,
                    'parallelism': 'replicas sharded over %d GPU(s), no data-path collective, one all-reduce of D* accumulators (%s)'
@@ -687,7 +728,7 @@ def main():
         'exact_path_hops': m['n_exact'], 'stopped_replicas': m['stopped'],
         'd_star_mean': m['stats']['d_star'], 'd_star_std': m['stats']['error_star'], 'd_j_mean': m['stats']['d_j'],
         'stage_ms': {'table_fold': m['fold_ms'], 'rates_full': m['rates_ms']},
-        'long_launch_rank0': m['long_launch'],
+        'launch_steps': m['launch_steps'], 'per_step_launch_rank0': m['per_step_launch'],
     }
     if other is not None:
         out['other_scaling'] = other

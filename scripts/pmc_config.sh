@@ -13,10 +13,10 @@ mkdir -p $OUT
 cd /tmp
 export TMPDIR=/tmp
 TRACE_STEPS=400; [ "$CFG" = 4 ] && TRACE_STEPS=40
-BENCH="python3 $ROOT/bench.py --config $CFG --steps 6 --warmup 2 --no-cpu-baseline --no-long-launch"
+BENCH="python3 $ROOT/bench.py --config $CFG --steps 6 --warmup 2 --no-cpu-baseline --no-long-launch --launch-steps 1"
 # the trace pass runs many steps (launch groups need a few steps to drift apart, the first launches are cold); the
 # counter passes serialise the kernels anyway and take 6 + 2
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --config $CFG --steps $TRACE_STEPS --warmup 20 --no-cpu-baseline --no-long-launch > $OUT/trace.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --config $CFG --steps $TRACE_STEPS --warmup 20 --no-cpu-baseline --no-long-launch --launch-steps 1 > $OUT/trace.log 2>&1
 echo trace done
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 echo fetch done
