@@ -220,14 +220,16 @@ class KMCEngine:
         n = np.ascontiguousarray(np.broadcast_to(np.asarray(n_hops, dtype=np.int64), (self.R,)))
         self._chk(self._lib.kmc_run_counts(self._ctx, _ptr(n, C.c_int64), int(bool(presim)), int(seed)))
 
-    def scalars(self):
-        t = np.empty(self.R)
-        st = np.empty(self.R)
-        g = np.empty(self.R)
-        h = np.empty((self.R, 6), dtype=np.int64)
+    def scalars(self, fields=('time', 'step_time', 'gamma', 'hist')):
+        """Clock, last run's clock, total rate and direction histogram of every replica; `fields` limits the read-back
+        (each is a copy of its own: the per-step drop-in calls ask for what they return)."""
+        t = np.empty(self.R) if 'time' in fields else None
+        st = np.empty(self.R) if 'step_time' in fields else None
+        g = np.empty(self.R) if 'gamma' in fields else None
+        h = np.empty((self.R, 6), dtype=np.int64) if 'hist' in fields else None
         self._chk(self._lib.kmc_get_scalars(self._ctx, _ptr(t, C.c_double), _ptr(st, C.c_double),
                                             _ptr(g, C.c_double), _ptr(h, C.c_int64)))
-        return dict(time=t, step_time=st, gamma=g, hist=h)
+        return {k: v for k, v in dict(time=t, step_time=st, gamma=g, hist=h).items() if v is not None}
 
     def set_time(self, time):
         t = np.ascontiguousarray(np.broadcast_to(np.asarray(time, dtype=np.float64), (self.R,)))
@@ -271,12 +273,12 @@ class KMCEngine:
         self._chk(self._lib.kmc_get_barrier_stats(self._ctx, _ptr(b, C.c_double)))
         return dict(last=b[:, 0], sum=b[:, 1], min=b[:, 2], max=b[:, 3], count=b[:, 4])
 
-    def status(self):
-        s = np.empty(self.R, dtype=np.int32)
-        h = np.empty(self.R, dtype=np.int64)
-        e = np.empty(self.R, dtype=np.int64)
+    def status(self, fields=('status', 'hops_done', 'n_exact')):
+        s = np.empty(self.R, dtype=np.int32) if 'status' in fields else None
+        h = np.empty(self.R, dtype=np.int64) if 'hops_done' in fields else None
+        e = np.empty(self.R, dtype=np.int64) if 'n_exact' in fields else None
         self._chk(self._lib.kmc_get_status(self._ctx, _ptr(s, C.c_int32), _ptr(h, C.c_int64), _ptr(e, C.c_int64)))
-        return dict(status=s, hops_done=h, n_exact=e)
+        return {k: v for k, v in dict(status=s, hops_done=h, n_exact=e).items() if v is not None}
 
     def gamma_exact(self):
         g = np.empty(self.R)

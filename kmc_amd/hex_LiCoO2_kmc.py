@@ -235,10 +235,14 @@ def kmc_step(mc_lattice, input_distance_lattice, input_hop_probability_matrix, u
     draws = np.random.uniform(0, 1, size=(n_hops, 1 if presim else 2))
     if presim:
         draws = np.concatenate([draws, np.ones((n_hops, 1))], axis=1)
-    hist0 = eng.scalars()['hist'][0].copy()
-    bar0 = eng.barrier_stats()['count'][0] if not presim else 0
+    # the engine's running histogram and barrier count before this call: what the last call read back, while the state
+    # it left is still the one on the device (two read-backs less per call)
+    hist0 = res['hist'] if res is not None and 'hist' in res else eng.scalars(('hist',))['hist'][0].copy()
+    bar0 = 0
+    if not presim:            # (a presimulation step moves the count too and does not read it back: not cached across one)
+        bar0 = res['bar_count'] if res is not None and res.get('bar_count') is not None else eng.barrier_stats()['count'][0]
     eng.run(n_hops, presim=presim, draws=draws[None])
-    st = eng.status()
+    st = eng.status(('status',))
     if st['status'][0] & 1:
         raise IndexError('index %d is out of bounds for axis 0 with size %d'
                          % (nx * ny * 6, nx * ny * 6))               # the reference's failure at :494-506
@@ -248,16 +252,16 @@ def kmc_step(mc_lattice, input_distance_lattice, input_hop_probability_matrix, u
     vals = np.where(new_occ == 1, atom_types[1][0], atom_types[1][1]).astype(np.asarray(lat).dtype)
     np.asarray(lat)[...] = vals.reshape(np.asarray(lat).shape)          # in place, like :518-520
     P = eng.get_rates()[0].reshape(nx, ny, 1, 6)
-    sc = eng.scalars()
+    sc = eng.scalars(('step_time', 'hist'))
     hop_histogram += (sc['hist'][0] - hist0)                           # module global (:30, :535)
     if presim:
-        _resident[id(eng)] = dict(occ=new_occ, P=P.copy(), dist=None)
+        _resident[id(eng)] = dict(occ=new_occ, P=P.copy(), dist=None, hist=sc['hist'][0].copy(), bar_count=None)
         return (lat, P)
     t = eng.get_reference_tags()[0].reshape(nx, ny, 1, 3)
     dist = np.array(t, dtype=np.asarray(input_distance_lattice).dtype)
     # (the tags are resident only if the caller's dtype holds them exactly, which any integer or float dtype does)
-    _resident[id(eng)] = dict(occ=new_occ, P=P.copy(), dist=dist.copy())
     bar = eng.barrier_stats()
+    _resident[id(eng)] = dict(occ=new_occ, P=P.copy(), dist=dist.copy(), hist=sc['hist'][0].copy(), bar_count=bar['count'][0])
     if bar['count'][0] == bar0:
         # every selected index was 0: the reference's chosen_barrier is unbound (:495, :539)
         raise UnboundLocalError("local variable 'chosen_barrier' referenced before assignment")
