@@ -1,7 +1,7 @@
 """Per-segment cycle breakdown (s_memtime stamps, -DKMC_STAMPS build) of the hop loop at ONE replica per CU: hop_q64_kernel
 (what 256 replicas ran before round 3) against hop_lat_kernel (what they run now).
     python scripts/stamps.py --build                                                 (build container)
-    KMC_AMD_LIB=kmc_amd/libkmc_hip_stamps.so python scripts/stamps_lat.py [R] [hops]   (GPU box)
+    KMC_AMD_LIB=kmc_amd/libkmc_hip_stamps.so python scripts/stamps_lat.py [R] [hops] [kernels, e.g. 3 or 3,5]   (GPU box)
 """
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +19,10 @@ NAMES = {3: ['chunk setup + flush (draws, clock, tags)', 'row + quarter pick', '
              'direction: palette read (LDS), 6-lane scan, certify', 'geometry, fresh-key atomics, window key read, gather issue',
              'old leaves (LDS) + book-keeping in the gather\'s shadow', 'wait for the gather (L2), 3 adds, 8-lane tree, bpermute',
              'row scan, gamma', '(of the direction stage: palette words, palette read, 6-lane scan)']}
+ONLY = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else [3, 5]
 for which, label in ((3, 'hop_q64_kernel'), (5, 'hop_lat_kernel')):
+    if which not in ONLY:
+        continue
     eng = kmc_amd.KMCEngine(R, 64)
     eng.set_base_table(t['base512_normcons'], kmc_amd.tables.dumbbell_rate())
     eng.set_hop_kernel(which=which)
